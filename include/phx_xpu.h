@@ -1,0 +1,228 @@
+/*
+ * phx_xpu.h — C ABI of the MI355X (gfx950) path-tracing device for phosphorus.
+ *
+ * This is the drop-in boundary: a shared library (libphx_hip.so) exporting exactly
+ * what a `hip_t : xpu_t` backend of the reference needs.  The reference interface it
+ * replaces is `struct xpu_t` (reference src/xpu.hpp:12-40):
+ *
+ *     virtual void preprocess(const scene_t&)            -> phx_dev_preprocess
+ *     virtual void start(const scene_t&, frame_state_t&) -> phx_dev_start
+ *     virtual void join()                                -> phx_dev_join
+ *     static T* make(const parsed_options_t&)            -> phx_dev_make   (src/xpu/cpu.hpp:35, src/xpu/cuda.hpp:12)
+ *     virtual ~xpu_t()                                   -> phx_dev_destroy
+ *     static discover(const parsed_options_t&)           -> phx_discover   (src/xpu.cpp:7-9)
+ *
+ * Plain C types only: pointers + sizes, no C++/torch types, int status codes instead of the
+ * reference's exceptions (std::runtime_error in utils/allocator.hpp:37-39 and kernels/cpu/spt.hpp:230).
+ * All arrays passed to phx_dev_preprocess are copied; the caller may free them afterwards
+ * (the reference device also rebuilds its own BVH in preprocess, src/xpu/cpu.cpp:35-44,219).
+ */
+#ifndef PHX_XPU_H
+#define PHX_XPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------- */
+enum {
+  PHX_OK            = 0,
+  PHX_ERR_ARG       = 1, /* bad argument / malformed scene */
+  PHX_ERR_DEVICE    = 2, /* HIP error; see phx_last_error() */
+  PHX_ERR_NO_DEVICE = 3, /* no gfx950 device visible */
+  PHX_ERR_STATE     = 4, /* call order violated (start before preprocess, ...) */
+  PHX_ERR_OOM       = 5  /* device arena exhausted ("Out of memory", utils/allocator.hpp:37) */
+};
+
+/* ---- ray / interaction flag bits (reference src/state.hpp:33-36) ------------------- */
+enum { PHX_HIT = 1, PHX_MASKED = 2, PHX_SHADOW = 4, PHX_SPECULAR = 8 };
+
+/* ---- closure ids (reference src/bsdf.hpp:14-24) and lobe flags (src/bsdf/params.hpp:12-16) */
+enum {
+  PHX_LOBE_EMISSIVE = 0, PHX_LOBE_DIFFUSE = 1, PHX_LOBE_OREN_NAYAR = 2, PHX_LOBE_REFLECTION = 4,
+  PHX_LOBE_REFRACTION = 8, PHX_LOBE_MICROFACET = 16, PHX_LOBE_SHEEN = 32, PHX_LOBE_BACKGROUND = 64,
+  PHX_LOBE_TRANSPARENT = 128
+};
+enum { PHX_BSDF_DIFFUSE = 1, PHX_BSDF_GLOSSY = 2, PHX_BSDF_SPECULAR = 4, PHX_BSDF_REFLECT = 8, PHX_BSDF_TRANSMIT = 16 };
+#define PHX_MAX_LOBES 8 /* bsdf_t::MaxLobes, src/bsdf.hpp:9 */
+
+/* ---- options: parsed_options_t (reference src/options.hpp:6-43) + device knobs ------- */
+typedef struct phx_options {
+  uint32_t samples_per_pixel; /* default 16 */
+  uint32_t paths_per_sample;  /* default 16; only scales the film by 1/pps (src/xpu/cpu.cpp:191) */
+  uint32_t path_depth;        /* default 9 */
+  uint32_t single_threaded;   /* honoured by CPU devices only */
+  uint32_t host_only;         /* --no-gpu: phx_discover returns 0 devices */
+  uint32_t render_normals;
+  uint32_t verbose;
+  /* device additions (0 = auto) */
+  int32_t  device_ordinal;    /* HIP device index; -1 = current device */
+  uint32_t samples_in_flight; /* samples of one pixel carried per wavefront pass */
+  uint32_t tiles_per_batch;   /* tiles pulled from the queue per pass */
+  uint32_t reserved[6];
+} phx_options;
+
+/* ---- scene: what the device reads through scene_t (src/scene.hpp:14-50) --------------- */
+
+/* One closure of a flattened closure tree (the output contract of material_t::evaluate,
+ * src/material.cpp:218-305,419-458, with constant inputs; shading normal = interpolated N). */
+typedef struct phx_lobe {
+  uint32_t type;      /* PHX_LOBE_* */
+  float    weight[3]; /* accumulated colour weight */
+  float    alpha;     /* OrenNayar: sigma (treated as degrees, src/bsdf/params.hpp:38) */
+  float    eta;       /* Reflection / Refraction / Microfacet */
+  float    xalpha;    /* Microfacet roughness inputs BEFORE precompute() (params.hpp:86-99) */
+  float    yalpha;
+  uint32_t refract;   /* Microfacet: 1 = transmissive */
+  float    r;         /* Sheen roughness */
+  uint32_t pad;
+} phx_lobe;
+
+typedef struct phx_material {
+  uint32_t num_lobes;   /* 0 for pure emitters (diffuse_emitter_node.osl) */
+  uint32_t is_emitter;  /* material_t::is_emitter, src/material.cpp:487 */
+  float    emission[3]; /* weight of the emission()/background() closure: hits.e */
+  uint32_t pad[3];
+  phx_lobe lobes[PHX_MAX_LOBES];
+} phx_material;
+
+/* mesh_t::face_set_t, src/mesh.hpp:26-41 */
+typedef struct phx_face_set {
+  uint32_t        material;  /* index into phx_scene.materials */
+  uint32_t        num_faces;
+  const uint32_t* faces;     /* face indices (not multiplied by 3) */
+} phx_face_set;
+
+/* mesh_t, src/mesh.hpp:14-138; mesh id = index in phx_scene.meshes (src/scene.cpp:79-82) */
+typedef struct phx_mesh {
+  const float*    vertices;  /* xyz per vertex */
+  uint32_t        num_vertices;
+  const float*    normals;   /* xyz; per vertex, or per face-corner when !NORMALS_PER_VERTEX */
+  uint32_t        num_normals;
+  const uint32_t* faces;     /* 3 vertex indices per face */
+  uint32_t        num_faces;
+  const uint8_t*  smooth;    /* per face: 1 = interpolate normals, 0 = geometric normal (mesh.cpp:187-206) */
+  uint32_t        flags;     /* PHX_MESH_* */
+  uint32_t        num_sets;
+  const phx_face_set* sets;
+} phx_mesh;
+enum { PHX_MESH_UV_PER_VERTEX = 1, PHX_MESH_NORMALS_PER_VERTEX = 2 }; /* mesh_t::flags_t, src/mesh.hpp:20-23 */
+
+/* camera_t, src/entities/camera.hpp:10-39.  Pinhole only (aperture_radius must be 0: the
+ * reference thin-lens path is broken, SURVEY A-21). */
+typedef struct phx_camera {
+  float    to_world[16]; /* Imath::M44f x[i][j], row-vector convention v' = v * M */
+  float    fov;
+  float    focal_distance;
+  float    aperture_radius;
+  uint32_t film_width;
+  uint32_t film_height;
+} phx_camera;
+
+typedef struct phx_scene {
+  uint32_t            num_meshes;
+  const phx_mesh*     meshes;
+  uint32_t            num_materials;
+  const phx_material* materials;
+  int32_t             environment_material; /* -1 = none (scene_t::environment, src/scene.cpp:126) */
+  phx_camera          camera;
+} phx_scene;
+
+/* ---- frame: frame_state_t {sampler, tiles, film} (src/state.hpp:18-31) --------------- */
+typedef struct phx_tile { uint32_t x, y, w, h; } phx_tile; /* job::tiles_t::tile_t, src/jobs/tiles.hpp:12-19 */
+
+/* job::tiles_t::next (src/jobs/tiles.hpp:40-47): returns 1 and fills *out, or 0 when drained.
+ * Called from the device's driver thread; must be thread safe (devices share one queue,
+ * src/core.cpp:103-108). */
+typedef int (*phx_next_tile_fn)(void* user, phx_tile* out);
+
+/* film_t<>::add_tile (src/film.hpp:12-15): `buffer` is the tile's interleaved fp32
+ * render_buffer_t (src/buffer.hpp:8-97): pixel (x,y) at buffer[y*ystride + x*xstride + c].
+ * Called from the device's driver thread. */
+typedef void (*phx_add_tile_fn)(void* user, int32_t x, int32_t y, int32_t w, int32_t h,
+                                const float* buffer, uint32_t xstride, uint32_t ystride);
+
+typedef struct phx_frame {
+  void*            tiles_user;
+  phx_next_tile_fn next_tile;
+  void*            film_user;
+  phx_add_tile_fn  add_tile;        /* may be NULL when device_film is set */
+  uint64_t         sampler_seed;    /* seed of the counter-based sampler (replaces sampler_t's mt19937) */
+  uint32_t         primary_components; /* components of channel "primary": 3 or 4 (3 are written, buffer.cpp:25-30) */
+  uint32_t         normals_channel;    /* 1: append channel "normals" x3 (cpu.cpp:194-196) */
+  /* optional: accumulate straight into a full-frame device-resident film (W*H*xstride fp32 in HBM,
+   * e.g. a torch tensor's data_ptr) — used for the multi-GPU film reduce. */
+  float*           device_film;
+  uint32_t         reserved[4];
+} phx_frame;
+
+/* ---- statistics ------------------------------------------------------------------------ */
+typedef struct phx_stats {
+  uint64_t camera_samples;   /* primary rays generated */
+  uint64_t rays_closest;     /* non-masked slots presented to closest-hit trace */
+  uint64_t rays_shadow;      /* non-masked shadow rays traced */
+  uint64_t rays_masked;      /* shadow rays masked before trace (src/kernels/cpu/spt.hpp:138-141) */
+  uint64_t tiles;
+  uint64_t trace_launches;   /* closest + any-hit kernel launches */
+  double   trace_ms;         /* sum of HIP-event durations of the trace kernels (closest + shadow) */
+  double   closest_ms;
+  double   shadow_ms;
+  double   shade_ms;         /* generate + shade/NEE + integrate + film kernels */
+  double   frame_ms;         /* wall time start..join on the host */
+  uint64_t bvh_nodes;
+  uint64_t bvh_bytes;
+  uint64_t triangles;
+  uint64_t reserved[8];
+} phx_stats;
+
+typedef struct phx_device phx_device; /* opaque */
+
+/* ---- the xpu_t surface ----------------------------------------------------------------- */
+/* xpu_t::discover (src/xpu.cpp:7-9): number of usable gfx950 devices (0 when options->host_only). */
+int         phx_discover(const phx_options* options, int* num_devices);
+/* T::make(const parsed_options_t&) (src/xpu/cpu.hpp:35).  NULL on failure (see phx_last_error). */
+phx_device* phx_dev_make(const phx_options* options);
+/* xpu_t::preprocess (src/xpu.hpp:20; cpu.cpp:219 -> details_t::reset :35): flatten + upload scene, build BVH. */
+int         phx_dev_preprocess(phx_device* dev, const phx_scene* scene);
+/* xpu_t::start (src/xpu.hpp:26; cpu.cpp:223-238): non-blocking; spawns the driver thread. */
+int         phx_dev_start(phx_device* dev, const phx_frame* frame);
+/* xpu_t::join (src/xpu.hpp:32; cpu.cpp:240): blocks; returns the frame's status. */
+int         phx_dev_join(phx_device* dev);
+/* ~xpu_t */
+void        phx_dev_destroy(phx_device* dev);
+
+const char* phx_last_error(void);
+int         phx_dev_get_stats(const phx_device* dev, phx_stats* out);
+
+/* ---- native tile queue: job::tiles_t (src/jobs/tiles.hpp:10-90) ----------------------- */
+/* make(): row-major tile_size x tile_size tiles with edge remainders (tiles.hpp:49-89);
+ * rank/world shard the queue for multi-GPU: tile i belongs to rank (i % world). */
+typedef struct phx_tiles phx_tiles;
+phx_tiles*  phx_tiles_make(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t world);
+int         phx_tiles_next(void* tiles /* phx_tiles* */, phx_tile* out); /* a phx_next_tile_fn */
+uint32_t    phx_tiles_count(const phx_tiles* tiles);
+void        phx_tiles_reset(phx_tiles* tiles);
+void        phx_tiles_free(phx_tiles* tiles);
+
+/* ---- stage-level entry points (used by the parity tests; all synchronous) ------------- */
+/* Closest-hit (shadow==0) or any-hit (shadow==1) trace of n host rays against the device BVH:
+ * the device equivalent of stream_mbvh_kernel_t::trace (kernels/cpu/stream_bvh_kernel.cpp:159).
+ * o,d: xyz per ray; tmax per ray.  Outputs: t (hit distance, or tmax on miss), u,v, prim
+ * (index into scene_t::triangles() order, 0xffffffff on miss; for any-hit 0/1-style hit flag in hit[]). */
+int phx_dev_trace(phx_device* dev, uint32_t n, const float* o, const float* d, const float* tmax,
+                  int shadow, float* t, float* u, float* v, uint32_t* prim, uint8_t* hit);
+
+/* bsdf_t::f (src/bsdf.cpp:113-131) and bsdf_t::sample (:133-248) evaluated on the device for
+ * material `material` with shading normal n[i]: KAT hooks.  Vectors are xyz per item. */
+int phx_dev_bsdf_f(phx_device* dev, uint32_t material, uint32_t n_items, const float* n,
+                   const float* wi, const float* wo, float* f_out);
+int phx_dev_bsdf_sample(phx_device* dev, uint32_t material, uint32_t n_items, const float* n,
+                        const float* wi, const float* u2, float* wo_out, float* f_out,
+                        float* pdf_out, uint32_t* flags_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHX_XPU_H */

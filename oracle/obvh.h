@@ -1,0 +1,381 @@
+// ORACLE — test infrastructure only.  Never linked into or called by the product path.
+//
+// obvh.h: the reference's 8-wide BVH, restated.
+//   * node / packet layout: mbvh::node_t<8> (src/accel/bvh/node.hpp:12-68, 288 B) and
+//     accel::triangle::moeller_trumbore_t<8> (src/accel/triangle.hpp:25-68, 384 B)
+//   * builder: bvh::from / find / split / largest_node (src/accel/bvh/binned_sah_builder.hpp:143-281)
+//     and the adapter accel::builder_t (src/accel/bvh.cpp:22-79)
+//   * traversal: MBVH-RS stream traversal `intersect` (src/kernels/cpu/stream_bvh_kernel.cpp:18-148,
+//     detail/stream.hpp:16-111), slab test simd::intersect<8> (src/math/simd/aabb.hpp:26-62),
+//     Moeller-Trumbore iterate_rays / iterate_triangles (src/accel/triangle.hpp:126-287)
+//   * brute force: linear_mbvh_kernel_t (src/kernels/cpu/linear_bvh_kernel.cpp:14-19)
+// Counters (node visits, packet visits) define V_n / V_l of SURVEY §8(d).
+#pragma once
+#include "oscene.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+#if defined(__x86_64__)
+#include <xmmintrin.h>
+#endif
+
+namespace orc {
+
+static const uint32_t F_HIT = 1, F_MASKED = 2, F_SHADOW = 4, F_SPECULAR = 8;  // state.hpp:33-36
+
+// numeric modes (SURVEY §7 hard part 2)
+struct modes_t {
+  int rcp_approx = 0;   // 1: use the x86 RCPPS approximation where the reference does (this CPU only)
+  int slab_literal = 0; // 1: reference slab test verbatim; 0: conservative (padded) slab test — never
+                        //    loses a Moeller-Trumbore hit, so results do not depend on BVH topology
+};
+
+struct node8_t {  // node.hpp:12-35
+  float bounds[48];
+  uint32_t offset[8];
+  uint8_t num[8];
+  uint32_t flags[8];
+  uint8_t pad[24];
+  node8_t() {
+    for (int i = 0; i < 24; ++i) { bounds[i] = FLT_MAX; bounds[i + 24] = -FLT_MAX; }
+    std::memset(offset, 0, sizeof(offset)); std::memset(num, 0, sizeof(num));
+    std::memset(flags, 0, sizeof(flags)); std::memset(pad, 0, sizeof(pad));
+  }
+  void set_bounds(uint32_t i, const Box3& b) {
+    bounds[i] = b.min.x; bounds[i + 8] = b.min.y; bounds[i + 16] = b.min.z;
+    bounds[i + 24] = b.max.x; bounds[i + 32] = b.max.y; bounds[i + 40] = b.max.z;
+  }
+};
+static_assert(sizeof(node8_t) == 288, "reference node_t<8> is 288 B (SURVEY App. C)");
+
+struct packet8_t {  // triangle.hpp:33-68
+  float e0x[8], e0y[8], e0z[8], e1x[8], e1y[8], e1z[8], v0x[8], v0y[8], v0z[8];
+  uint32_t num;
+  uint32_t meshid[8];
+  uint32_t faceid[8];
+  uint32_t prim[8];  // oracle extra: index into scene.triangles() order (not part of the 384 B)
+};
+
+// ---- builder ---------------------------------------------------------------------------------
+struct primitive_t { uint32_t index; Box3 bounds; V3 centroid; };
+
+struct geometry_t {  // binned_sah_builder.hpp:23-75
+  std::vector<primitive_t>* prims;
+  uint32_t start, end;
+  Box3 bounds, centroid_bounds;
+  geometry_t() : prims(nullptr), start(0), end(0) {}
+  explicit geometry_t(std::vector<primitive_t>* p) : prims(p), start(0), end(0) {}
+  geometry_t(std::vector<primitive_t>* p, uint32_t s, uint32_t e) : prims(p), start(s), end(e) {
+    for (uint32_t i = s; i < e; ++i) { bounds.extendBy((*p)[i].bounds); centroid_bounds.extendBy((*p)[i].centroid); }
+  }
+  uint32_t count() const { return end - start; }
+};
+
+inline float box_area(const Box3& b) {  // aabb::area, math/aabb.hpp:11-14 (2.0 is a double)
+  V3 d = b.max - b.min;
+  return (float)(2.0 * (double)(d.x * d.y + d.x * d.z + d.y * d.z));
+}
+inline uint32_t bin_of(const Box3& l, const primitive_t& p, int axis) {  // bins_t::offset/find :113-124
+  V3 o = p.centroid - l.min;
+  if (l.max.x > l.min.x) o.x /= (l.max.x - l.min.x);
+  if (l.max.y > l.min.y) o.y /= (l.max.y - l.min.y);
+  if (l.max.z > l.min.z) o.z /= (l.max.z - l.min.z);
+  return (uint32_t)std::min((int)(12 * o[axis]), 11);
+}
+struct split_t { uint32_t axis, bin; float cost; };
+
+inline split_t find_split(const geometry_t& g) {  // bvh::find :143-189
+  uint32_t best_axis = 0, best_bin = 0;
+  float best_cost = FLT_MAX;
+  for (int axis = 0; axis < 3; ++axis) {
+    struct { uint32_t count = 0; Box3 bounds; } bins[12];
+    if (g.centroid_bounds.max[axis] < g.centroid_bounds.min[axis]) continue;
+    for (uint32_t i = 0; i < g.count(); ++i) {
+      const primitive_t& p = (*g.prims)[g.start + i];
+      auto& b = bins[bin_of(g.centroid_bounds, p, axis)];
+      b.bounds.extendBy(p.bounds); b.count++;
+    }
+    float split_cost = FLT_MAX; uint32_t split_bin = 0;
+    for (int i = 0; i < 11; ++i) {
+      Box3 a, b; int left = 0, right = 0;
+      for (int j = 0; j <= i; ++j) { a.extendBy(bins[j].bounds); left += bins[j].count; }
+      for (int j = i + 1; j < 12; ++j) { b.extendBy(bins[j].bounds); right += bins[j].count; }
+      float cost = (left * box_area(a) + right * box_area(b)) / box_area(g.bounds);
+      if (cost < split_cost) { split_cost = cost; split_bin = i; }
+    }
+    if (split_cost < best_cost) { best_axis = axis; best_cost = split_cost; best_bin = split_bin; }
+  }
+  return split_t{best_axis, best_bin, best_cost};
+}
+
+inline void do_split(const split_t& s, geometry_t& parent, geometry_t& l, geometry_t& r) {  // bvh::split :191-196
+  std::vector<primitive_t>& P = *parent.prims;
+  const Box3 cb = parent.centroid_bounds;
+  auto* first = &P[0] + parent.start;
+  auto* last = &P[0] + parent.end;  // &primitives[end-1]+1
+  auto* mid = std::partition(first, last, [&](const primitive_t& p) { return bin_of(cb, p, s.axis) <= s.bin; });
+  uint32_t m = (uint32_t)(mid - &P[0]);
+  l = geometry_t(parent.prims, parent.start, m);
+  r = geometry_t(parent.prims, m, parent.end);
+}
+
+struct bvh8_t {
+  std::vector<node8_t> nodes;
+  std::vector<packet8_t> packets;
+  bool has_root = false;
+
+  uint32_t add(uint32_t begin, uint32_t end, const std::vector<primitive_t>& prims, const std::vector<tri_ref_t>& tris) {
+    uint32_t off = (uint32_t)packets.size();  // accel::builder_t::add, bvh.cpp:58-78
+    for (uint32_t i = begin; i < end; i += 8) {
+      uint32_t num = std::min(8u, end - i);
+      packet8_t pk; std::memset(&pk, 0, sizeof(pk));
+      pk.num = num;
+      for (uint32_t j = 0; j < num; ++j) {
+        const tri_ref_t& t = tris[prims[i + j].index];
+        const V3 a = t.a(), b = t.b(), c = t.c();
+        const V3 e0 = b - a, e1 = c - a;
+        pk.e0x[j] = e0.x; pk.e0y[j] = e0.y; pk.e0z[j] = e0.z;
+        pk.e1x[j] = e1.x; pk.e1y[j] = e1.y; pk.e1z[j] = e1.z;
+        pk.v0x[j] = a.x; pk.v0y[j] = a.y; pk.v0z[j] = a.z;
+        pk.meshid[j] = t.meshid() | (t.matid() << 16);
+        pk.faceid[j] = t.face;
+        pk.prim[j] = prims[i + j].index;
+      }
+      packets.push_back(pk);
+    }
+    return off;
+  }
+
+  // bvh::from(geometry, things, bvh), binned_sah_builder.hpp:215-270
+  uint32_t build_rec(geometry_t& g, const std::vector<tri_ref_t>& tris) {
+    split_t s = find_split(g);
+    if (g.count() < 8 || (float)g.count() <= 1.0f + s.cost) return 0;
+    int num_children = 2;
+    geometry_t children[8];
+    for (auto& c : children) c = geometry_t(g.prims);
+    do_split(s, g, children[0], children[1]);
+    while (num_children < 8) {
+      int split_child = -1;  // largest_node :198-213 — picks the SMALLEST area child with >= 8 prims
+      float a = FLT_MAX;
+      for (int i = 0; i < num_children; ++i) {
+        if (children[i].count() < 8) continue;
+        float na = box_area(children[i].bounds);
+        if (na < a) { split_child = i; a = na; }
+      }
+      if (split_child == -1) break;
+      split_t s2 = find_split(children[split_child]);
+      geometry_t tmp(g.prims);
+      do_split(s2, children[split_child], tmp, children[num_children]);
+      children[split_child] = tmp;
+      ++num_children;
+    }
+    nodes.emplace_back();
+    uint32_t node_index = (uint32_t)nodes.size() - 1;
+    uint32_t child_indices[8];
+    for (int i = 0; i < num_children; ++i) child_indices[i] = build_rec(children[i], tris);
+    for (int i = 0; i < num_children; ++i) {
+      node8_t& node = nodes[node_index];
+      node.set_bounds(i, children[i].bounds);
+      if (child_indices[i]) {
+        node.offset[i] = child_indices[i];
+      } else {
+        uint32_t index = add(children[i].start, children[i].end, *g.prims, tris);
+        node8_t& nd = nodes[node_index];
+        nd.flags[i] = 1; nd.offset[i] = index; nd.num[i] = (uint8_t)children[i].count();
+      }
+    }
+    return node_index;
+  }
+
+  void build(const std::vector<tri_ref_t>& tris) {  // bvh::from(builder, things) :272-281
+    nodes.clear(); packets.clear();
+    std::vector<primitive_t> prims(tris.size());
+    for (uint32_t i = 0; i < tris.size(); ++i) { prims[i].index = i; prims[i].bounds = tris[i].bounds(); prims[i].centroid = prims[i].bounds.center(); }
+    geometry_t g(&prims, 0, (uint32_t)prims.size());
+    build_rec(g, tris);
+    has_root = !nodes.empty();  // SURVEY A-13: < 8 triangles (or cheap leaf) leaves no root node
+  }
+};
+
+// ---- ray stream (ray_t<N>, state.hpp:40-169) as a plain SoA of arbitrary length ----------------
+struct rays_t {
+  std::vector<float> px, py, pz, wx, wy, wz, d, u, v;
+  std::vector<uint32_t> mesh, face, flags, prim;
+  void resize(size_t n) {
+    px.resize(n); py.resize(n); pz.resize(n); wx.resize(n); wy.resize(n); wz.resize(n); d.resize(n); u.resize(n); v.resize(n);
+    mesh.resize(n); face.resize(n); flags.resize(n); prim.resize(n, 0xffffffffu);
+  }
+  size_t size() const { return d.size(); }
+  V3 p(uint32_t i) const { return V3(px[i], py[i], pz[i]); }
+  V3 wi(uint32_t i) const { return V3(wx[i], wy[i], wz[i]); }
+  bool is_hit(uint32_t i) const { return (flags[i] & F_HIT) == F_HIT; }
+  bool is_masked(uint32_t i) const { return (flags[i] & F_MASKED) == F_MASKED; }
+  bool is_shadow(uint32_t i) const { return (flags[i] & F_SHADOW) == F_SHADOW; }
+  bool is_specular(uint32_t i) const { return (flags[i] & F_SPECULAR) == F_SPECULAR; }
+  bool is_occluded(uint32_t i) const { return is_hit(i) || is_masked(i); }
+  uint32_t meshid(uint32_t i) const { return mesh[i] & 0xffffu; }
+  uint32_t matid(uint32_t i) const { return (mesh[i] & 0xffff0000u) >> 16; }
+};
+
+struct trace_counters_t { uint64_t rays = 0, node_visits = 0, packet_visits = 0; };
+
+#if defined(__x86_64__)
+inline float rcp_approx(float x) { return _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(x))); }
+#else
+inline float rcp_approx(float x) { return 1.0f / x; }
+#endif
+
+// one ray against one triangle of a packet: the body of iterate_rays / iterate_triangles
+// (triangle.hpp:149-164 and :232-247 are the same arithmetic)
+inline bool mt_test(const packet8_t& pk, int j, const V3& o, const V3& wi, float dmax, float& us, float& vs, float& ds) {
+  const V3 e0(pk.e0x[j], pk.e0y[j], pk.e0z[j]), e1(pk.e1x[j], pk.e1y[j], pk.e1z[j]), v0(pk.v0x[j], pk.v0y[j], pk.v0z[j]);
+  const V3 t = o - v0;
+  const V3 p = sv::cross(wi, e1);
+  const float det = sv::dot(e0, p);
+  const float ood = 1.0f / det;
+  const V3 q = sv::cross(t, e0);
+  us = sv::dot(t, p) * ood;
+  vs = sv::dot(wi, q) * ood;
+  ds = sv::dot(e1, q) * ood;
+  const bool xmask = (det > 0.00000001f) || (det < -0.00000001f);
+  const bool umask = us >= 0.0f;
+  const bool vmask = (vs >= 0.0f) && ((us + vs) <= 1.0f);
+  const bool dmask = (ds >= 0.0f) && (ds < dmax);
+  return vmask && umask && dmask && xmask;
+}
+
+// packet vs. one ray, closest-of-packet by strict '<' in lane order (triangle.hpp:166-198)
+inline void packet_vs_ray(const packet8_t& pk, rays_t& R, uint32_t index) {
+  const V3 o = R.p(index), wi = R.wi(index);
+  float closest = R.d[index];
+  int idx = -1; float bu = 0, bv = 0;
+  for (int j = 0; j < (int)pk.num; ++j) {
+    float us, vs, ds;
+    if (mt_test(pk, j, o, wi, R.d[index], us, vs, ds) && ds < closest) { closest = ds; idx = j; bu = us; bv = vs; }
+  }
+  if (idx != -1) {
+    if (!R.is_shadow(index)) { R.mesh[index] = pk.meshid[idx]; R.face[index] = pk.faceid[idx]; R.u[index] = bu; R.v[index] = bv; R.prim[index] = pk.prim[idx]; }
+    R.flags[index] |= F_HIT; R.d[index] = closest;  // ray_t::hit, state.hpp:118-123
+  }
+}
+
+// simd::intersect<8> for one child box (aabb.hpp:26-62); ood = 1/dir (or RCPPS in approx mode)
+inline bool slab_literal(const node8_t& n, int c, const V3& o, const V3& ood, float d, float& dist) {
+  const float bminx = n.bounds[c], bminy = n.bounds[c + 8], bminz = n.bounds[c + 16];
+  const float bmaxx = n.bounds[c + 24], bmaxy = n.bounds[c + 32], bmaxz = n.bounds[c + 40];
+  // select(m,l,r) = blendv(l,r,m): picks r where the mask is set (float8.hpp:103)
+  float nx = (ood.x >= 0.0f) ? bminx : bmaxx, fx = (ood.x >= 0.0f) ? bmaxx : bminx;
+  float ny = (ood.y >= 0.0f) ? bminy : bmaxy, fy = (ood.y >= 0.0f) ? bmaxy : bminy;
+  float nz = (ood.z >= 0.0f) ? bminz : bmaxz, fz = (ood.z >= 0.0f) ? bmaxz : bminz;
+  nx = (nx - o.x) * ood.x; ny = (ny - o.y) * ood.y; nz = (nz - o.z) * ood.z;
+  fx = (fx - o.x) * ood.x; fy = (fy - o.y) * ood.y; fz = (fz - o.z) * ood.z;
+  // _mm256_max_ps(a,b) = a > b ? a : b (returns b on NaN)
+  auto mx = [](float a, float b) { return a > b ? a : b; };
+  auto mn = [](float a, float b) { return a < b ? a : b; };
+  const float nn = mx(mx(nx, ny), mx(nz, 0.0f));
+  const float ff = mn(mn(fx, fy), mn(fz, d));
+  dist = nn;
+  return nn <= ff;
+}
+// conservative variant: IEEE maxNum/minNum (NaN-ignoring) and both ends padded by 4 ulp, so a
+// rounding error in (b-o)*ood can never reject a box that contains a true hit point
+inline bool slab_conservative(const node8_t& n, int c, const V3& o, const V3& ood, float d, float& dist) {
+  const float bminx = n.bounds[c], bminy = n.bounds[c + 8], bminz = n.bounds[c + 16];
+  const float bmaxx = n.bounds[c + 24], bmaxy = n.bounds[c + 32], bmaxz = n.bounds[c + 40];
+  float nx = (ood.x >= 0.0f) ? bminx : bmaxx, fx = (ood.x >= 0.0f) ? bmaxx : bminx;
+  float ny = (ood.y >= 0.0f) ? bminy : bmaxy, fy = (ood.y >= 0.0f) ? bmaxy : bminy;
+  float nz = (ood.z >= 0.0f) ? bminz : bmaxz, fz = (ood.z >= 0.0f) ? bmaxz : bminz;
+  nx = (nx - o.x) * ood.x; ny = (ny - o.y) * ood.y; nz = (nz - o.z) * ood.z;
+  fx = (fx - o.x) * ood.x; fy = (fy - o.y) * ood.y; fz = (fz - o.z) * ood.z;
+  float nn = std::fmax(std::fmax(nx, ny), std::fmax(nz, 0.0f));
+  float ff = std::fmin(std::fmin(fx, fy), std::fmin(fz, d));
+  dist = nn;
+  nn = nn - std::fabs(nn) * 4.76837158203125e-7f;  // 4 ulp
+  ff = ff + std::fabs(ff) * 4.76837158203125e-7f;
+  return nn <= ff;
+}
+
+// MBVH-RS stream traversal over R[0..num) (stream_bvh_kernel.cpp:18-148).  Slots are traced
+// unless MASKED (lanes_t::init, stream.hpp:25-32).
+struct stream_tracer_t {
+  const bvh8_t* bvh;
+  modes_t modes;
+  std::vector<uint32_t> lanes[8];
+  std::vector<uint32_t> lane_num;  // unused; lanes[i].size() is the fill
+  struct task_t { uint32_t offset, num_rays, lane, flags, prims; };
+  std::vector<task_t> tasks;
+  trace_counters_t ctr;
+
+  explicit stream_tracer_t(const bvh8_t* b, modes_t m = modes_t()) : bvh(b), modes(m) {}
+
+  void trace(rays_t& R, uint32_t num) {
+    for (auto& l : lanes) l.clear();
+    tasks.clear();
+    for (uint32_t i = 0; i < num; ++i) if (!R.is_masked(i)) lanes[0].push_back(i);
+    ctr.rays += lanes[0].size();
+    if (lanes[0].empty() || !bvh->has_root) return;
+    tasks.push_back(task_t{0, (uint32_t)lanes[0].size(), 0, 0, 0});
+    std::vector<uint32_t> todo;
+    while (!tasks.empty()) {
+      task_t cur = tasks.back(); tasks.pop_back();
+      // pop(lanes, cur.lane, cur.num_rays), stream.hpp:105-110
+      std::vector<uint32_t>& L = lanes[cur.lane];
+      todo.assign(L.end() - cur.num_rays, L.end());
+      L.resize(L.size() - cur.num_rays);
+      if (cur.flags != 1) {
+        const node8_t& node = bvh->nodes[cur.offset];
+        int num_active[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float length[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t ray : todo) {
+          if (R.is_shadow(ray) && R.is_hit(ray)) continue;  // any-hit early out, :61-64
+          const V3 o = R.p(ray), w = R.wi(ray);
+          V3 ood = modes.rcp_approx ? V3(rcp_approx(w.x), rcp_approx(w.y), rcp_approx(w.z)) : V3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
+          ++ctr.node_visits;
+          for (int c = 0; c < 8; ++c) {
+            float dist;
+            bool h = modes.slab_literal ? slab_literal(node, c, o, ood, R.d[ray], dist) : slab_conservative(node, c, o, ood, R.d[ray], dist);
+            if (h) { num_active[c] += 1; length[c] += dist; lanes[c].push_back(ray); }
+          }
+        }
+        // insertion sort of the hit children by summed entry distance, :99-115 (verbatim: the
+        // inner loop compares d with dists[ids[j]] and never stops early)
+        uint32_t ids[8]; int n = 0;
+        for (int i = 0; i < 8; ++i) {
+          if (num_active[i] > 0) {
+            float d = length[i];
+            ids[n] = i;
+            for (int j = n; j > 0; --j) {
+              if (d < length[ids[j]]) { uint32_t t = ids[j]; ids[j] = ids[j - 1]; ids[j - 1] = t; }
+            }
+            ++n;
+          }
+        }
+        for (int i = 0; i < n; ++i)
+          tasks.push_back(task_t{node.offset[ids[i]], (uint32_t)num_active[ids[i]], ids[i], node.flags[ids[i]], node.num[ids[i]]});
+      } else {
+        // leaf: groups of <= 8 rays x the leaf's packets, :122-145
+        for (size_t begin = 0; begin < todo.size(); begin += 8) {
+          size_t nr = std::min(todo.size() - begin, (size_t)8);
+          uint32_t index = cur.offset; uint32_t prims = 0;
+          do {
+            if (index < bvh->packets.size()) {  // guard for the empty-leaf quirk (count 0 leaves)
+              for (size_t r = 0; r < nr; ++r) { ++ctr.packet_visits; packet_vs_ray(bvh->packets[index], R, todo[begin + r]); }
+            }
+            prims += 8; ++index;
+          } while (prims < cur.prims);
+        }
+      }
+    }
+  }
+};
+
+// linear_mbvh_kernel_t: every non-masked ray against every packet (linear_bvh_kernel.cpp:14-19)
+inline void trace_brute(const bvh8_t& bvh, rays_t& R, uint32_t num) {
+  for (uint32_t i = 0; i < num; ++i) {
+    if (R.is_masked(i)) continue;
+    for (const packet8_t& pk : bvh.packets) packet_vs_ray(pk, R, i);
+  }
+}
+
+}  // namespace orc

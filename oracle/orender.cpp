@@ -1,0 +1,612 @@
+// ORACLE — test infrastructure only.  Never linked into or called by the product path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so.
+//
+// orender.cpp: CPU restatement of the reference's hot path behind a small C API (ctypes):
+//   tile_renderer_t::render_tile / trace_rays      src/xpu/cpu.cpp:48-206
+//   camera::perspective_kernel_t                   src/kernels/cpu/camera.hpp:78-159
+//   deferred_shading_kernel_t                      src/kernels/cpu/deferred_shading_kernel.hpp:20-72
+//   spt::light_sampler_t / integrator_t            src/kernels/cpu/spt.hpp:95-328
+//   sampler_t (mt19937 stream, stratified jitter)  src/sampling.cpp:43-179, src/math/sampling.hpp:65-77
+//   job::tiles_t::make                             src/jobs/tiles.hpp:49-89
+//
+// PARITY STATUS: "parity unpinned" for everything that needs Imath / OpenImageIO / OSL — the
+// reference ships no tests or golden vectors and cannot be compiled in this image
+// without writing stand-ins for those absent third-party headers, so this restatement is anchored
+// only on (a) the dependency-free reference headers compiled verbatim into oracle/_ref
+// (fresnel::dielectric, simd float8 select/compare semantics, __bscf), (b) the survey's recorded
+// run statistics of the real reference (rays per camera sample, BVH visits per ray, mt19937 head),
+// and (c) line-by-line citations.
+//
+// Two RNG modes: RNG_SEQ replays the reference's single sequential mt19937 stream in reference
+// order (1 thread, 1024-slot streams, stale-slot quirk of edge tiles included); RNG_COUNTER draws
+// every number from a counter hash of (seed, pixel, sample, dimension) — the mode the HIP device
+// implements and is compared against bit for bit.
+#include "obsdf.h"
+#include "obvh.h"
+#include "orng.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+using namespace orc;
+
+namespace {
+
+const uint32_t STREAM = 1024;  // config::STREAM_SIZE, math/config.hpp:6
+
+struct interactions_t {  // interaction_t<1024>, state.hpp:182-234 (xform/s/t feed only OSL)
+  std::vector<V3> p, wi, n, e;
+  std::vector<uint32_t> flags;
+  std::vector<int32_t> material;  // -1: bsdf == nullptr
+  std::vector<bsdf_t> bsdf;
+  void resize(size_t k) { p.assign(k, V3()); wi.assign(k, V3()); n.assign(k, V3()); e.assign(k, V3()); flags.assign(k, 0); material.assign(k, -1); bsdf.assign(k, bsdf_t()); }
+  bool is_hit(uint32_t i) const { return (flags[i] & F_HIT) == F_HIT; }
+  bool is_specular(uint32_t i) const { return (flags[i] & F_SPECULAR) == F_SPECULAR; }
+};
+
+struct state_t {  // spt::state_t<1024>, spt.hpp:23-64
+  uint16_t depth[STREAM];
+  float pdf[STREAM];
+  V3 beta[STREAM], r[STREAM];
+  void reset() { for (uint32_t i = 0; i < STREAM; ++i) { depth[i] = 0; r[i] = V3(0.0f); beta[i] = V3(1.0f); } }
+};
+
+struct render_args_t {
+  int32_t rng_mode;       // 0 = RNG_SEQ, 1 = RNG_COUNTER
+  int32_t rcp_approx;     // see modes_t
+  int32_t slab_literal;
+  int32_t num_threads;    // RNG_COUNTER only
+  uint64_t seed;
+  uint32_t sample_begin;  // render samples [sample_begin, sample_end) of options.samples_per_pixel
+  uint32_t sample_end;    // 0 = all
+  uint32_t num_tiles;     // 0 = all tiles of the film (tiles_t::make, 32x32)
+  const phx_tile* tiles;
+};
+
+struct stats_t {
+  uint64_t camera_samples, rays_closest, rays_shadow, rays_masked;
+  uint64_t node_visits_closest, packet_visits_closest, node_visits_shadow, packet_visits_shadow;
+  uint64_t rng_draws;
+  double seconds;
+  uint64_t bvh_nodes, bvh_packets;
+};
+
+struct oracle_t {
+  scene_t scene;
+  phx_options opt;
+  bvh8_t bvh;
+  float sheen_L5 = 0.0f;
+};
+
+// job::tiles_t::make, tiles.hpp:49-89
+std::vector<phx_tile> make_tiles(uint32_t width, uint32_t height, uint32_t ts) {
+  uint32_t ht = width / ts, vt = height / ts;
+  const uint32_t rh = height - ts * vt, rw = width - ts * ht;
+  if (rh > 0) vt++;
+  if (rw > 0) ht++;
+  std::vector<phx_tile> out;
+  for (uint32_t y = 0; y < vt; ++y)
+    for (uint32_t x = 0; x < ht; ++x) {
+      uint32_t tw = ts, th = ts;
+      if (y == vt - 1 && rh > 0) th = rh;
+      if (x == ht - 1 && rw > 0) tw = rw;
+      out.push_back(phx_tile{x * ts, y * ts, tw, th});
+    }
+  return out;
+}
+
+struct jitter_t { std::vector<V2> film; };
+
+// sampler_t::preprocess, sampling.cpp:89-143, in RNG_SEQ: consumes the stream exactly as the reference
+void sampler_preprocess_seq(seq_rng_t& rng, uint32_t spp, uint32_t nlights, jitter_t& J) {
+  const uint32_t spd = (uint32_t)std::lroundf(std::sqrt((float)spp));
+  J.film.assign(spp, V2(0.0f, 0.0f));  // defined: entries >= spd*spd are uninitialised stack in the reference (A-4)
+  const float step = 1.0f / (float)spd;
+  float dy = 0.0f;
+  for (uint32_t i = 0; i < spd; ++i, dy += step) {  // sample::stratified_2d, math/sampling.hpp:65-77
+    float dx = 0.0f;
+    for (uint32_t j = 0; j < spd; ++j, dx += step) {
+      float a = dx + rng.sample() * step;
+      float b = dy + rng.sample() * step;
+      if (j * spd + i < spp) J.film[j * spd + i] = V2(a, b);
+    }
+  }
+  for (uint32_t i = 0; i < spp; ++i) for (int k = 0; k < 128 * 8 * 2; ++k) rng.sample();  // lens table
+  (void)nlights;
+  for (int i = 0; i < 64 * 1024 * 3; ++i) rng.sample();  // 64 never-used light sample sets
+}
+// the same table from the counter RNG: one jitter per spp index, shared by every pixel (A-4)
+void sampler_preprocess_counter(uint64_t seed, uint32_t spp, jitter_t& J) {
+  const uint32_t spd = (uint32_t)std::lroundf(std::sqrt((float)spp));
+  J.film.assign(spp, V2(0.0f, 0.0f));
+  const float step = 1.0f / (float)spd;
+  float dy = 0.0f;
+  for (uint32_t i = 0; i < spd; ++i, dy += step) {
+    float dx = 0.0f;
+    for (uint32_t j = 0; j < spd; ++j, dx += step) {
+      const uint32_t cell = j * spd + i;
+      const uint32_t key = path_key(seed, FILM_JITTER_STREAM, cell);
+      float a = dx + draw_f32(key, 0) * step;
+      float b = dy + draw_f32(key, 1) * step;
+      if (cell < spp) J.film[cell] = V2(a, b);
+    }
+  }
+}
+
+struct tile_renderer_t {
+  const oracle_t& O;
+  const render_args_t& A;
+  modes_t modes;
+  seq_rng_t* seq;  // RNG_SEQ only
+  const jitter_t& J;
+  rays_t rays;
+  interactions_t primary, hits;
+  state_t st;
+  uint32_t active_num = 0;
+  uint32_t active_index[STREAM];
+  stream_tracer_t tracer;
+  stats_t S{};
+  uint32_t cur_sample = 0;
+  phx_tile cur_tile{};
+  uint32_t W, H;
+
+  tile_renderer_t(const oracle_t& o, const render_args_t& a, seq_rng_t* s, const jitter_t& j)
+      : O(o), A(a), seq(s), J(j), tracer(&o.bvh) {
+    modes.rcp_approx = a.rcp_approx; modes.slab_literal = a.slab_literal;
+    tracer.modes = modes;
+    W = o.scene.camera.film_width; H = o.scene.camera.film_height;
+  }
+
+  // per-path counter key: pixel = film pixel of slot k of the current tile
+  uint32_t key_of_pixel(uint32_t k) const {
+    const uint32_t x = cur_tile.x + k % cur_tile.w, y = cur_tile.y + k / cur_tile.w;
+    return path_key(A.seed, y * W + x, cur_sample);
+  }
+
+  float inv_len(float l2) const { return modes.rcp_approx ? rcp_approx(std::sqrt(l2)) : 1.0f / std::sqrt(l2); }
+
+  // camera::perspective_kernel_t::operator(), camera.hpp:80-159 (pinhole branch)
+  void camera_rays(const phx_tile& tile, const V2& jit) {
+    const phx_camera& cam = O.scene.camera;
+    const float* M = cam.to_world;  // x[i][j] = M[4*i+j]
+    const float zoom = 1.12f * std::tan(cam.fov * 0.5f);
+    const float stepx = 1.0f / (float)cam.film_width, stepy = 1.0f / (float)cam.film_height;
+    const float ratio = (float)cam.film_width / (float)cam.film_height;
+    uint32_t off = 0;
+    float sy = (float)tile.y;
+    for (uint32_t y = 0; y < tile.h; ++y) {
+      const float ndcy = 0.5f - (-0.5f + sy) * stepy;
+      float sx0 = (float)tile.x;
+      for (uint32_t x = 0; x < tile.w; ++x, ++off) {
+        // px = tile.x + seqv; sx advances by 8.0f per group: lane value = tile.x + (x%8) + 8*(x/8) = exact ints
+        const float sx = ((float)tile.x + (float)(x % 8)) + (float)(8 * (x / 8));
+        (void)sx0;
+        const float ndcx = (-0.5f + sx) * stepx - 0.5f;
+        V3 d(jit.x, jit.y, -1.0f);
+        d.x = (ndcx + d.x * stepx) * ratio * zoom;
+        d.y = (ndcy + d.y * stepy) * zoom;
+        const float ool = inv_len(sv::dot(d, d));  // vector3_t::normalize, simd/vector.hpp:126-133
+        d = V3(d.x * ool, d.y * ool, d.z * ool);
+        // transform_point(m, 0) and transform_vector(m, d), simd/matrix.hpp:58-104
+        V3 p;
+        { float t = 0.0f * M[0]; t = std::fmaf(0.0f, M[4], t); t = std::fmaf(0.0f, M[8], t); p.x = t + M[12]; }
+        { float t = 0.0f * M[1]; t = std::fmaf(0.0f, M[5], t); t = std::fmaf(0.0f, M[9], t); p.y = t + M[13]; }
+        { float t = 0.0f * M[2]; t = std::fmaf(0.0f, M[6], t); t = std::fmaf(0.0f, M[10], t); p.z = t + M[14]; }
+        V3 w;
+        { float t = d.x * M[0]; t = std::fmaf(d.y, M[4], t); w.x = std::fmaf(d.z, M[8], t); }
+        { float t = d.x * M[1]; t = std::fmaf(d.y, M[5], t); w.y = std::fmaf(d.z, M[9], t); }
+        { float t = d.x * M[2]; t = std::fmaf(d.y, M[6], t); w.z = std::fmaf(d.z, M[10], t); }
+        rays.px[off] = p.x; rays.py[off] = p.y; rays.pz[off] = p.z;
+        rays.wx[off] = w.x; rays.wy[off] = w.y; rays.wz[off] = w.z;
+        rays.d[off] = FLT_MAX; rays.flags[off] = 0;
+      }
+      sy = sy + 1.0f;
+    }
+  }
+
+  void trace(bool shadow_pass) {
+    trace_counters_t before = tracer.ctr;
+    tracer.trace(rays, active_num);
+    uint64_t nrays = tracer.ctr.rays - before.rays;
+    if (shadow_pass) {
+      S.rays_shadow += nrays; S.rays_masked += active_num - nrays;
+      S.node_visits_shadow += tracer.ctr.node_visits - before.node_visits;
+      S.packet_visits_shadow += tracer.ctr.packet_visits - before.packet_visits;
+    } else {
+      S.rays_closest += nrays;
+      S.node_visits_closest += tracer.ctr.node_visits - before.node_visits;
+      S.packet_visits_closest += tracer.ctr.packet_visits - before.packet_visits;
+    }
+  }
+
+  // deferred_shading_kernel_t::operator(), deferred_shading_kernel.hpp:20-72 + material_t::evaluate
+  // (material.cpp:419-458) reduced to its output contract: closure recipe -> bsdf_t, e
+  void shade(interactions_t& out) {
+    const scene_t& sc = O.scene;
+    for (uint32_t i = 0; i < active_num; ++i) {
+      out.flags[i] = rays.flags[i];
+      const V3 p = rays.p(i), wi = rays.wi(i);
+      out.p[i] = p + wi * rays.d[i];
+      out.e[i] = V3(0.0f);
+      int32_t material = -2;  // -2: not shaded (bsdf pointer keeps its stale value in the reference)
+      if (rays.is_hit(i)) {
+        const mesh_t& mesh = sc.meshes[rays.meshid(i)];
+        material = (int32_t)rays.matid(i);
+        out.wi[i] = -wi;
+        out.n[i] = mesh.shading_normal(rays.face[i], rays.u[i], rays.v[i]);
+      } else {
+        out.wi[i] = wi;
+        if (sc.env_material >= 0) material = sc.env_material;
+      }
+      if (material >= 0) {
+        const phx_material& m = sc.materials[material];
+        out.e[i] = V3(m.emission[0], m.emission[1], m.emission[2]);
+        out.material[i] = material;
+        out.bsdf[i].from_material(m, out.n[i]);
+        out.bsdf[i].sheen_L5 = O.sheen_L5;
+      }
+    }
+  }
+
+  // sampler_t::fresh_light_samples (sampling.cpp:160-179) for ONE slot
+  void light_sample_from(float pick, const V2& uv, light_sample_t& s, float& pdf) const {
+    const uint32_t nlights = (uint32_t)O.scene.lights.size();
+    const uint32_t l = std::min((uint32_t)std::floor(pick * nlights), nlights - 1);
+    O.scene.lights[l].sample(uv, s);
+    pdf = s.pdf / nlights;
+  }
+
+  // spt::light_sampler_t::operator(), spt.hpp:95-149
+  void prepare_occlusion_queries(interactions_t& out) {
+    std::vector<light_sample_t> ls(STREAM);
+    std::vector<float> lpdf(STREAM);
+    uint32_t upto = ((active_num + 7) / 8) * 8;  // the loop works on whole groups of 8 slots
+    if (upto > STREAM) upto = STREAM;
+    if (A.rng_mode == 0) {
+      for (uint32_t k = 0; k < STREAM; ++k) {  // always 1024 samples, 3 draws each
+        const float pick = seq->sample();
+        const float a = seq->sample(); const float b = seq->sample();
+        light_sample_from(pick, V2(a, b), ls[k], lpdf[k]);
+      }
+    } else {
+      upto = active_num;
+      for (uint32_t k = 0; k < active_num; ++k) {
+        const uint32_t pixel = active_index[k];
+        const uint32_t key = key_of_pixel(pixel);
+        const uint32_t b = st.depth[pixel] * DIMS_PER_STEP;
+        light_sample_from(draw_f32(key, b + DIM_LIGHT_PICK), V2(draw_f32(key, b + DIM_LIGHT_U), draw_f32(key, b + DIM_LIGHT_V)), ls[k], lpdf[k]);
+      }
+    }
+    for (uint32_t i = 0; i < upto; ++i) {
+      rays.mesh[i] = ls[i].mesh; rays.face[i] = ls[i].face; rays.u[i] = ls[i].uv.x; rays.v[i] = ls[i].uv.y;
+      const V3 n = out.n[i];
+      const V3 hp = out.p[i];
+      const V3 p(hp.x + n.x * 0.0001f, hp.y + n.y * 0.0001f, hp.z + n.z * 0.0001f);  // simd::offset, simd/vector.hpp:223-231
+      V3 wi = ls[i].p - p;
+      const float l2 = sv::dot(wi, wi);
+      const float d = std::sqrt(l2) - 0.0001f;
+      const float ool = inv_len(l2);
+      wi = V3(wi.x * ool, wi.y * ool, wi.z * ool);
+      const bool is_hit = (out.flags[i] & F_HIT) == F_HIT;
+      const bool ish = sv::dot(n, wi) >= 0.0f;  // simd::in_same_hemisphere, simd/vector.hpp:233-237
+      const uint32_t flags = (is_hit && ish) ? F_SHADOW : (F_MASKED | F_SHADOW);  // select(mask, masked, shadow)
+      rays.px[i] = p.x; rays.py[i] = p.y; rays.pz[i] = p.z;
+      rays.wx[i] = wi.x; rays.wy[i] = wi.y; rays.wz[i] = wi.z;
+      rays.d[i] = d; rays.flags[i] = flags;
+      st.pdf[i] = lpdf[i];
+    }
+  }
+
+  // spt::integrator_t::li, spt.hpp:212-255
+  V3 li(const interactions_t& out, uint32_t to) const {
+    const V3 wi = rays.wi(to), wo = out.wi[to];
+    const float d = rays.d[to];
+    if (out.material[to] < 0) return V3(0.0f);  // reference throws "NO BSDF!" (spt.hpp:230)
+    const V3 f = out.bsdf[to].f(wi, wo);
+    const mesh_t& mesh = O.scene.meshes[rays.meshid(to)];
+    const phx_material& lm = O.scene.materials[rays.matid(to)];
+    const V3 light_n = mesh.shading_normal(rays.face[to], rays.u[to], rays.v[to]);
+    const V3 le(lm.emission[0], lm.emission[1], lm.emission[2]);
+    const float pdf = st.pdf[to] * d * d / std::fabs(light_n.dot(-wi));
+    return (le * 4.0f) * f * (1.0f / pdf);
+  }
+
+  static float luminance(const V3& c) {  // color::y, utils/color.hpp:13-16
+    static const float w[3] = {0.212671, 0.715160, 0.072169};
+    return w[0] * c.x + w[1] * c.y + w[2] * c.z;
+  }
+
+  // terminate_path, spt.hpp:307-328
+  bool terminate_path(uint32_t index, uint32_t key) {
+    float w = 1.0f;
+    const V3 beta = st.beta[index];
+    bool alive = st.depth[index] < O.opt.path_depth;
+    if (alive) {
+      if (st.depth[index] >= 3) {
+        const float q = std::max(0.05f, 1.0f - luminance(beta));
+        const float xi = (A.rng_mode == 0) ? seq->sample() : draw_f32(key, (st.depth[index] - 1u) * DIMS_PER_STEP + DIM_RR);
+        alive = xi >= q;
+        if (alive) w = (1.0f / (1.0f - q));
+      }
+    }
+    st.beta[index] = beta * w;
+    return !alive;
+  }
+
+  // sample_bsdf, spt.hpp:257-305
+  bool sample_bsdf(const interactions_t& out, uint32_t index, uint32_t from, uint32_t to) {
+    const uint32_t key = (A.rng_mode == 0) ? 0u : key_of_pixel(index);
+    if (terminate_path(index, key)) return false;
+    const V3 p = out.p[from], wi = out.wi[from], n = out.n[from];
+    const V3 beta = st.beta[index];
+    if (out.material[from] < 0) return false;
+    V2 s;
+    if (A.rng_mode == 0) { s.x = seq->sample(); s.y = seq->sample(); }
+    else { const uint32_t b = (st.depth[index] - 1u) * DIMS_PER_STEP; s = V2(draw_f32(key, b + DIM_BSDF_U), draw_f32(key, b + DIM_BSDF_V)); }
+    uint32_t flags; float pdf; V3 sampled;
+    const V3 f = out.bsdf[from].sample(s, wi, sampled, pdf, flags);
+    if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) return false;
+    const float weight = n.dot(sampled);
+    st.beta[index] = beta * (f * (std::fabs(weight) / pdf));
+    const float off = (weight < 0.0f) ? -0.0001f : 0.0001f;  // offset(), math/vector.hpp:14-21
+    const V3 np = p + n * off;
+    rays.px[to] = np.x; rays.py[to] = np.y; rays.pz[to] = np.z;
+    rays.wx[to] = sampled.x; rays.wy[to] = sampled.y; rays.wz[to] = sampled.z;
+    rays.d[to] = FLT_MAX; rays.flags[to] = 0;
+    if ((flags & PHX_BSDF_SPECULAR) == PHX_BSDF_SPECULAR) rays.flags[to] |= F_SPECULAR; else rays.flags[to] &= ~F_SPECULAR;
+    return true;
+  }
+
+  // integrator_t::operator(), spt.hpp:161-210
+  void integrate(interactions_t& out) {
+    const uint32_t num = active_num;
+    active_num = 0;
+    for (uint32_t i = 0; i < num; ++i) {
+      const uint32_t index = active_index[i];
+      V3 o = st.r[index];
+      if (out.is_hit(i)) {
+        if (st.depth[index] == 0 || out.is_specular(i)) o += st.beta[index] * out.e[i];
+        if (!rays.is_occluded(i)) o += st.beta[index] * li(out, i);
+        ++st.depth[index];
+        if (sample_bsdf(out, index, i, active_num)) active_index[active_num++] = index;
+      } else {
+        o += st.beta[index] * out.e[i];
+      }
+      st.r[index] = o;
+    }
+  }
+
+  void trace_rays(interactions_t& out) {  // cpu.cpp:148-154
+    trace(false);
+    shade(out);
+    prepare_occlusion_queries(out);
+    trace(true);
+    integrate(out);
+  }
+
+  void render_tile(const phx_tile& tile, float* film, float* normals) {  // cpu.cpp:156-205
+    cur_tile = tile;
+    rays = rays_t(); rays.resize(STREAM);            // new(allocator) ray_t<>() value-initialises
+    primary.resize(STREAM); hits.resize(STREAM);
+    const uint32_t spp = O.opt.samples_per_pixel, pps = O.opt.paths_per_sample;
+    const uint32_t s0 = A.sample_begin, s1 = A.sample_end ? A.sample_end : spp;
+    const float inv = 1.0f / (float)(spp * pps);
+    std::vector<V3> acc((size_t)tile.w * tile.h, V3(0.0f));
+    for (uint32_t j = s0; j < s1; ++j) {
+      cur_sample = j;
+      // prepare_sample, cpu.cpp:116-131: active.reset(0) always covers all 1024 slots (A-1); the
+      // counter mode only tracks the tile's real pixels
+      active_num = (A.rng_mode == 0) ? STREAM : tile.w * tile.h;
+      for (uint32_t i = 0; i < STREAM; ++i) active_index[i] = i;
+      st.reset();
+      camera_rays(tile, J.film[j]);
+      S.camera_samples += (uint64_t)tile.w * tile.h;
+      trace_rays(primary);
+      while (active_num > 0) trace_rays(hits);
+      for (uint32_t y = 0; y < tile.h; ++y)
+        for (uint32_t x = 0; x < tile.w; ++x) {
+          const uint32_t k = y * tile.w + x;
+          acc[k] += st.r[k] * inv;
+          if (normals && primary.is_hit(k)) {
+            float* np = normals + 3 * ((size_t)(tile.y + y) * W + tile.x + x);
+            np[0] = primary.n[k].x; np[1] = primary.n[k].y; np[2] = primary.n[k].z;
+          }
+        }
+    }
+    for (uint32_t y = 0; y < tile.h; ++y)  // film_t<>::add_tile: 4 components, alpha untouched
+      for (uint32_t x = 0; x < tile.w; ++x) {
+        float* fp = film + 4 * ((size_t)(tile.y + y) * W + tile.x + x);
+        const V3& c = acc[y * tile.w + x];
+        fp[0] = c.x; fp[1] = c.y; fp[2] = c.z;
+      }
+  }
+};
+
+void add_stats(stats_t& a, const stats_t& b) {
+  a.camera_samples += b.camera_samples; a.rays_closest += b.rays_closest; a.rays_shadow += b.rays_shadow; a.rays_masked += b.rays_masked;
+  a.node_visits_closest += b.node_visits_closest; a.packet_visits_closest += b.packet_visits_closest;
+  a.node_visits_shadow += b.node_visits_shadow; a.packet_visits_shadow += b.packet_visits_shadow;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* orc_create(const phx_scene* scene, const phx_options* options) {
+  oracle_t* o = new oracle_t();
+  if (!o->scene.load(scene) || !options) { delete o; return nullptr; }
+  o->opt = *options;
+  std::vector<tri_ref_t> tris;
+  o->scene.triangles(tris);
+  o->bvh.build(tris);  // cpu_t::preprocess -> details_t::reset, cpu.cpp:35-44
+  for (auto& m : o->scene.materials)
+    for (uint32_t i = 0; i < m.num_lobes; ++i)
+      if (m.lobes[i].type == PHX_LOBE_SHEEN) { o->sheen_L5 = sheen_L(0.5f, m.lobes[i].r); goto done; }
+done:
+  return o;
+}
+void orc_destroy(void* h) { delete (oracle_t*)h; }
+
+int orc_bvh_info(void* h, uint64_t* nodes, uint64_t* packets, uint64_t* triangles) {
+  oracle_t* o = (oracle_t*)h;
+  *nodes = o->bvh.nodes.size(); *packets = o->bvh.packets.size();
+  uint64_t t = 0; for (auto& p : o->bvh.packets) t += p.num;
+  *triangles = t;
+  return 0;
+}
+
+// film: W*H*4 fp32 (zero-initialised by the caller), normals: W*H*3 or NULL
+int orc_render(void* h, const render_args_t* args, float* film, float* normals, stats_t* stats) {
+  oracle_t* o = (oracle_t*)h;
+  if (!o || !args || !film) return 1;
+  if (o->scene.lights.empty()) return 2;  // A-19: nlights-1 underflows
+  if (o->scene.camera.aperture_radius != 0.0f) return 3;
+  const uint32_t W = o->scene.camera.film_width, H = o->scene.camera.film_height;
+  std::vector<phx_tile> tiles = args->num_tiles ? std::vector<phx_tile>(args->tiles, args->tiles + args->num_tiles) : make_tiles(W, H, 32);
+  for (auto& t : tiles) if (t.w * t.h > STREAM || t.w % 8 != 0) return 4;  // A-2
+  stats_t total{};
+  auto t0 = std::chrono::steady_clock::now();
+  jitter_t J;
+  if (args->rng_mode == 0) {
+    seq_rng_t rng;
+    sampler_preprocess_seq(rng, o->opt.samples_per_pixel, (uint32_t)o->scene.lights.size(), J);
+    tile_renderer_t R(*o, *args, &rng, J);
+    for (auto& t : tiles) R.render_tile(t, film, normals);
+    total = R.S; total.rng_draws = rng.draws;
+  } else {
+    sampler_preprocess_counter(args->seed, o->opt.samples_per_pixel, J);
+    int nt = args->num_threads > 0 ? args->num_threads : 1;
+    std::atomic<uint32_t> cursor{0};
+    std::vector<stats_t> per(nt);
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; ++k)
+      th.emplace_back([&, k]() {
+        tile_renderer_t R(*o, *args, nullptr, J);
+        for (;;) {
+          uint32_t t = cursor++;
+          if (t >= tiles.size()) break;
+          R.render_tile(tiles[t], film, normals);
+        }
+        per[k] = R.S;
+      });
+    for (auto& t : th) t.join();
+    for (auto& p : per) add_stats(total, p);
+  }
+  total.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  total.bvh_nodes = o->bvh.nodes.size(); total.bvh_packets = o->bvh.packets.size();
+  if (stats) *stats = total;
+  return 0;
+}
+
+// per-spp film jitter table of the counter sampler (spp entries, x then y)
+int orc_jitter_table(uint64_t seed, uint32_t spp, float* out_xy) {
+  jitter_t J; sampler_preprocess_counter(seed, spp, J);
+  for (uint32_t i = 0; i < spp; ++i) { out_xy[2 * i] = J.film[i].x; out_xy[2 * i + 1] = J.film[i].y; }
+  return 0;
+}
+
+// stream trace of a ray dump, in chunks of 1024 slots like the reference streams.
+// flags_in: 0 or F_SHADOW per ray.  mode: 0 = MBVH-RS, 1 = brute force over all packets.
+int orc_trace(void* h, uint32_t n, const float* o3, const float* d3, const float* tmax, const uint32_t* flags_in,
+              int mode, int slab_literal, int rcp_apx, float* t, float* u, float* v, uint32_t* prim, uint32_t* flags_out,
+              uint64_t* counters /* rays, node_visits, packet_visits */) {
+  oracle_t* o = (oracle_t*)h;
+  modes_t md; md.slab_literal = slab_literal; md.rcp_approx = rcp_apx;
+  stream_tracer_t tr(&o->bvh, md);
+  rays_t R;
+  for (uint32_t base = 0; base < n; base += STREAM) {
+    const uint32_t cnt = std::min(STREAM, n - base);
+    R = rays_t(); R.resize(cnt);
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t g = base + i;
+      R.px[i] = o3[3 * g]; R.py[i] = o3[3 * g + 1]; R.pz[i] = o3[3 * g + 2];
+      R.wx[i] = d3[3 * g]; R.wy[i] = d3[3 * g + 1]; R.wz[i] = d3[3 * g + 2];
+      R.d[i] = tmax[g]; R.flags[i] = flags_in ? flags_in[g] : 0;
+    }
+    if (mode == 0) tr.trace(R, cnt); else trace_brute(o->bvh, R, cnt);
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t g = base + i;
+      t[g] = R.d[i]; u[g] = R.u[i]; v[g] = R.v[i]; prim[g] = R.prim[i]; flags_out[g] = R.flags[i];
+    }
+  }
+  if (counters) { counters[0] = tr.ctr.rays; counters[1] = tr.ctr.node_visits; counters[2] = tr.ctr.packet_visits; }
+  return 0;
+}
+
+// ---- known-answer entry points ---------------------------------------------------------------
+int orc_bsdf_f(void* h, uint32_t material, uint32_t n_items, const float* n3, const float* wi3, const float* wo3, float* f3) {
+  oracle_t* o = (oracle_t*)h;
+  if (material >= o->scene.materials.size()) return 1;
+  for (uint32_t i = 0; i < n_items; ++i) {
+    bsdf_t b; b.from_material(o->scene.materials[material], V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2])); b.sheen_L5 = o->sheen_L5;
+    V3 f = b.f(V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]));
+    f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
+  }
+  return 0;
+}
+int orc_bsdf_sample(void* h, uint32_t material, uint32_t n_items, const float* n3, const float* wi3, const float* u2,
+                    float* wo3, float* f3, float* pdf, uint32_t* flags) {
+  oracle_t* o = (oracle_t*)h;
+  if (material >= o->scene.materials.size()) return 1;
+  for (uint32_t i = 0; i < n_items; ++i) {
+    bsdf_t b; b.from_material(o->scene.materials[material], V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2])); b.sheen_L5 = o->sheen_L5;
+    V3 wo(0.0f); float p = 0; uint32_t fl = 0;
+    V3 f = b.sample(V2(u2[2 * i], u2[2 * i + 1]), V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo, p, fl);
+    if (p == 0.0f) { wo = V3(0.0f); f = V3(0.0f); fl = 0; }  // terminated: outputs defined as zero
+    wo3[3 * i] = wo.x; wo3[3 * i + 1] = wo.y; wo3[3 * i + 2] = wo.z;
+    f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z; pdf[i] = p; flags[i] = fl;
+  }
+  return 0;
+}
+void orc_fresnel_dielectric(uint32_t n, const float* cosi, const float* eta, float* out) { for (uint32_t i = 0; i < n; ++i) out[i] = fresnel_dielectric(cosi[i], eta[i]); }
+void orc_onb(uint32_t n, const float* n3, float* abc9) {
+  for (uint32_t i = 0; i < n; ++i) {
+    onb_t b(V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]));
+    float* q = abc9 + 9 * i;
+    q[0] = b.a.x; q[1] = b.a.y; q[2] = b.a.z; q[3] = b.b.x; q[4] = b.b.y; q[5] = b.b.z; q[6] = b.c.x; q[7] = b.c.y; q[8] = b.c.z;
+  }
+}
+void orc_cosine_weighted(uint32_t n, const float* u2, float* out3, float* pdf) {
+  for (uint32_t i = 0; i < n; ++i) { V3 o; float p; cosine_weighted(V2(u2[2 * i], u2[2 * i + 1]), o, p); out3[3 * i] = o.x; out3[3 * i + 1] = o.y; out3[3 * i + 2] = o.z; pdf[i] = p; }
+}
+void orc_sincos(uint32_t n, const float* x, float* s, float* c) { for (uint32_t i = 0; i < n; ++i) { s[i] = m::sinf_(x[i]); c[i] = m::cosf_(x[i]); } }
+void orc_exp_log_pow(uint32_t n, const float* x, const float* y, float* e, float* l, float* p) {
+  for (uint32_t i = 0; i < n; ++i) { e[i] = m::expf_(x[i]); l[i] = m::logf_(x[i]); p[i] = m::powf_(x[i], y[i]); }
+}
+void orc_mt19937_head(uint32_t n, float* out) { seq_rng_t r; for (uint32_t i = 0; i < n; ++i) out[i] = r.sample(); }
+void orc_counter_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n_dims, float* out) {
+  uint32_t k = path_key(seed, pixel, sample);
+  for (uint32_t i = 0; i < n_dims; ++i) out[i] = draw_f32(k, i);
+}
+// area_light_t::sample through light pick (sampling.cpp:165-178): out = p(3) uv(2) pdf mesh face
+int orc_light_sample(void* h, uint32_t n, const float* pick, const float* u2, float* p3, float* uv2, float* pdf, uint32_t* mesh, uint32_t* face) {
+  oracle_t* o = (oracle_t*)h;
+  const uint32_t nl = (uint32_t)o->scene.lights.size();
+  if (!nl) return 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t l = std::min((uint32_t)std::floor(pick[i] * nl), nl - 1);
+    light_sample_t s; o->scene.lights[l].sample(V2(u2[2 * i], u2[2 * i + 1]), s);
+    p3[3 * i] = s.p.x; p3[3 * i + 1] = s.p.y; p3[3 * i + 2] = s.p.z; uv2[2 * i] = s.uv.x; uv2[2 * i + 1] = s.uv.y;
+    pdf[i] = s.pdf / nl; mesh[i] = s.mesh; face[i] = s.face;
+  }
+  return 0;
+}
+// flat copy of the reference-layout BVH (for the golden topology fixture)
+int orc_bvh_dump(void* h, float* node_bounds /*48/node*/, uint32_t* node_offset /*8*/, uint32_t* node_flags /*8*/, uint32_t* node_num /*8*/,
+                 uint32_t* packet_num, uint32_t* packet_prims /*8*/) {
+  oracle_t* o = (oracle_t*)h;
+  for (size_t i = 0; i < o->bvh.nodes.size(); ++i) {
+    const node8_t& nd = o->bvh.nodes[i];
+    for (int k = 0; k < 48; ++k) node_bounds[48 * i + k] = nd.bounds[k];
+    for (int k = 0; k < 8; ++k) { node_offset[8 * i + k] = nd.offset[k]; node_flags[8 * i + k] = nd.flags[k]; node_num[8 * i + k] = nd.num[k]; }
+  }
+  for (size_t i = 0; i < o->bvh.packets.size(); ++i) {
+    packet_num[i] = o->bvh.packets[i].num;
+    for (int k = 0; k < 8; ++k) packet_prims[8 * i + k] = k < (int)o->bvh.packets[i].num ? o->bvh.packets[i].prim[k] : 0xffffffffu;
+  }
+  return 0;
+}
+
+}  // extern "C"

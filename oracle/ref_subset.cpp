@@ -1,0 +1,49 @@
+// ORACLE — test infrastructure only.  Never linked into or called by the product path.
+//
+// ref_subset.cpp -> oracle/_ref/libphx_ref_subset.so
+//
+// The ONLY pieces of the reference that compile here without third-party code are the headers
+// that include nothing but the C++ standard library / x86 intrinsics.  They are compiled from
+// where they lie under /root/reference/src (never copied) and exported so that the restatement
+// can be checked against the reference's own object code for them:
+//   fresnel::dielectric          src/math/fresnel.hpp:6-28
+//   trig::radians                src/math/trigonometry.hpp:5-9
+//   simd::float_t<8> ops         src/math/simd/float8.hpp (select / compares / rcp / min / max)
+//   __bscf                       src/utils/compiler.hpp:6-14
+// Everything else of the hot path includes Imath / OpenImageIO / OSL headers, which this image
+// does not have: per the build rules that part is "unbuildable here" (no stand-in headers).
+#include <cstddef>
+#include <cstdint>
+#include <immintrin.h>
+
+#include "math/fresnel.hpp"
+#include "math/trigonometry.hpp"
+#include "math/simd/float8.hpp"
+#include "utils/compiler.hpp"
+
+extern "C" {
+
+void ref_fresnel_dielectric(uint32_t n, const float* cosi, const float* eta, float* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = fresnel::dielectric(cosi[i], eta[i]);
+}
+void ref_radians(uint32_t n, const float* a, float* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = trig::radians(a[i]);
+}
+// 8-wide helpers: all arrays have 8 floats
+void ref_select8(const float* mask_bits, const float* l, const float* r, float* out) {
+  simd::float_t<8> m(_mm256_loadu_ps(mask_bits)), a(_mm256_loadu_ps(l)), b(_mm256_loadu_ps(r));
+  _mm256_storeu_ps(out, simd::select(m, a, b).v);
+}
+void ref_cmp8(int op, const float* l, const float* r, float* out_bits) {
+  simd::float_t<8> a(_mm256_loadu_ps(l)), b(_mm256_loadu_ps(r));
+  simd::float_t<8> m = op == 0 ? (a < b) : op == 1 ? (a <= b) : op == 2 ? (a > b) : (a >= b);
+  _mm256_storeu_ps(out_bits, m.v);
+}
+void ref_minmax8(int is_max, const float* l, const float* r, float* out) {
+  simd::float_t<8> a(_mm256_loadu_ps(l)), b(_mm256_loadu_ps(r));
+  _mm256_storeu_ps(out, (is_max ? simd::max(a, b) : simd::min(a, b)).v);
+}
+void ref_rcp8(const float* x, float* out) { _mm256_storeu_ps(out, simd::rcp(simd::float_t<8>(_mm256_loadu_ps(x))).v); }
+uint64_t ref_bscf(uint64_t v, uint64_t* rest) { size_t x = v; size_t i = __bscf(x); *rest = x; return i; }
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+"""Scene descriptions handed to a device: the host-side stand-in for what the reference builds through
+`mesh_t::builder_t` (src/mesh.hpp:46-67) + `scene_t::add` (src/scene.cpp:64-90), and the synthetic
+inputs of SURVEY §8(d): the Cornell box (C1) and Soup(N, seed) triangle soups (C2/C4).
+
+A `SceneDesc` owns numpy arrays; `pack()` builds the ctypes `phx_scene` that points into them.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+from . import abi
+
+
+@dataclass
+class LobeDesc:
+    type: int
+    weight: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    alpha: float = 0.0
+    eta: float = 0.0
+    xalpha: float = 0.0
+    yalpha: float = 0.0
+    refract: int = 0
+    r: float = 0.0
+
+
+@dataclass
+class MaterialDesc:
+    lobes: List[LobeDesc] = field(default_factory=list)
+    emission: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    is_emitter: bool = False
+
+
+@dataclass
+class MeshDesc:
+    vertices: np.ndarray  # (n,3) f32
+    faces: np.ndarray     # (k,3) u32
+    sets: List[Tuple[int, np.ndarray]]  # (material, face indices u32)
+    normals: np.ndarray = None  # (m,3) f32
+    smooth: np.ndarray = None   # (k,) u8
+    flags: int = abi.MESH_UV_PER_VERTEX | abi.MESH_NORMALS_PER_VERTEX
+
+    def __post_init__(self):
+        self.vertices = np.ascontiguousarray(self.vertices, dtype=np.float32).reshape(-1, 3)
+        self.faces = np.ascontiguousarray(self.faces, dtype=np.uint32).reshape(-1, 3)
+        if self.normals is None:
+            self.normals = np.zeros((0, 3), np.float32)
+        self.normals = np.ascontiguousarray(self.normals, dtype=np.float32).reshape(-1, 3)
+        if self.smooth is None:
+            self.smooth = np.zeros(len(self.faces), np.uint8)
+        self.smooth = np.ascontiguousarray(self.smooth, dtype=np.uint8)
+        self.sets = [(int(m), np.ascontiguousarray(f, dtype=np.uint32)) for m, f in self.sets]
+
+
+@dataclass
+class CameraDesc:
+    width: int
+    height: int
+    fov: float = 1.9
+    to_world: np.ndarray = None  # Imath M44f x[i][j], row-vector convention
+    focal_distance: float = 1.0
+    aperture_radius: float = 0.0
+
+    def __post_init__(self):
+        if self.to_world is None:
+            self.to_world = np.eye(4, dtype=np.float32)
+        self.to_world = np.ascontiguousarray(self.to_world, dtype=np.float32).reshape(4, 4)
+
+
+@dataclass
+class SceneDesc:
+    meshes: List[MeshDesc]
+    materials: List[MaterialDesc]
+    camera: CameraDesc
+    environment_material: int = -1
+    name: str = "scene"
+
+    @property
+    def num_triangles(self):
+        return sum(sum(len(f) for _, f in m.sets) for m in self.meshes)
+
+    def pack(self):
+        """-> (abi.Scene, keepalive).  The ctypes struct borrows the numpy buffers."""
+        keep = []
+        mats = (abi.Material * len(self.materials))()
+        for i, m in enumerate(self.materials):
+            mats[i].num_lobes = len(m.lobes)
+            mats[i].is_emitter = 1 if m.is_emitter else 0
+            mats[i].emission[:] = [np.float32(x) for x in m.emission]
+            for j, l in enumerate(m.lobes):
+                d = mats[i].lobes[j]
+                d.type = l.type
+                d.weight[:] = [np.float32(x) for x in l.weight]
+                d.alpha, d.eta, d.xalpha, d.yalpha, d.refract, d.r = l.alpha, l.eta, l.xalpha, l.yalpha, l.refract, l.r
+        meshes = (abi.Mesh * len(self.meshes))()
+        for i, m in enumerate(self.meshes):
+            sets = (abi.FaceSet * len(m.sets))()
+            for k, (mat, faces) in enumerate(m.sets):
+                sets[k].material = mat
+                sets[k].num_faces = len(faces)
+                sets[k].faces = faces.ctypes.data_as(abi.u32p)
+            keep.append(sets)
+            meshes[i].vertices = m.vertices.ctypes.data_as(abi.f32p)
+            meshes[i].num_vertices = len(m.vertices)
+            meshes[i].normals = m.normals.ctypes.data_as(abi.f32p)
+            meshes[i].num_normals = len(m.normals)
+            meshes[i].faces = m.faces.ctypes.data_as(abi.u32p)
+            meshes[i].num_faces = len(m.faces)
+            meshes[i].smooth = m.smooth.ctypes.data_as(abi.u8p)
+            meshes[i].flags = m.flags
+            meshes[i].num_sets = len(m.sets)
+            meshes[i].sets = sets
+        s = abi.Scene()
+        s.num_meshes = len(self.meshes)
+        s.meshes = meshes
+        s.num_materials = len(self.materials)
+        s.materials = mats
+        s.environment_material = self.environment_material
+        s.camera.to_world[:] = [float(x) for x in self.camera.to_world.reshape(-1)]
+        s.camera.fov = self.camera.fov
+        s.camera.focal_distance = self.camera.focal_distance
+        s.camera.aperture_radius = self.camera.aperture_radius
+        s.camera.film_width = self.camera.width
+        s.camera.film_height = self.camera.height
+        keep += [mats, meshes, self]
+        return s, keep
+
+
+def diffuse(r, g, b):
+    return MaterialDesc(lobes=[LobeDesc(abi.LOBE_DIFFUSE, (r, g, b))])
+
+
+def emitter(r, g, b):
+    # diffuse_emitter_node.osl:18 -> only an emission() closure: 0 lobes, e = weight
+    return MaterialDesc(lobes=[], emission=(r, g, b), is_emitter=True)
+
+
+def _quad(a, b, c, d, material):
+    """One quad = its own mesh, 4 vertices, two flat faces (a,b,c),(a,c,d), one face set."""
+    v = np.array([a, b, c, d], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    return MeshDesc(vertices=v, faces=f, sets=[(material, np.array([0, 1], np.uint32))])
+
+
+LE = (17.0 / math.pi, 12.0 / math.pi, 4.0 / math.pi)
+
+
+def cornell(width=256, height=256, fov=1.9):
+    """C1: 5 diffuse quads + 1 emissive quad (12 triangles), camera at the origin looking down -z.
+
+    Geometric normals ((b-a) x (c-a), never flipped: src/mesh.cpp:203-215) face into the box so that
+    next-event estimation is not masked (src/kernels/cpu/spt.hpp:138-141).
+    """
+    W, R, G, L = 0, 1, 2, 3
+    mats = [diffuse(0.73, 0.73, 0.73), diffuse(0.65, 0.05, 0.05), diffuse(0.12, 0.45, 0.15), emitter(*LE)]
+    x0, x1, y0, y1, zf, zb = -1.0, 1.0, -1.0, 1.0, -1.5, -3.5
+    meshes = [
+        _quad((x0, y0, zf), (x1, y0, zf), (x1, y0, zb), (x0, y0, zb), W),   # floor, n = +y
+        _quad((x0, y1, zf), (x0, y1, zb), (x1, y1, zb), (x1, y1, zf), W),   # ceiling, n = -y
+        _quad((x0, y0, zb), (x1, y0, zb), (x1, y1, zb), (x0, y1, zb), W),   # back, n = +z
+        _quad((x0, y0, zf), (x0, y0, zb), (x0, y1, zb), (x0, y1, zf), R),   # left, n = +x
+        _quad((x1, y0, zf), (x1, y1, zf), (x1, y1, zb), (x1, y0, zb), G),   # right, n = -x
+        _quad((-0.25, 0.99, -2.25), (-0.25, 0.99, -2.75), (0.25, 0.99, -2.75), (0.25, 0.99, -2.25), L),  # lamp, n = -y
+    ]
+    return SceneDesc(meshes, mats, CameraDesc(width, height, fov), name="cornell")
+
+
+def _u01(idx, seed):
+    """Counter-based uniform [0,1) with 24 bits: splitmix64 finaliser of (seed, idx).  numpy uint64 wraps."""
+    with np.errstate(over="ignore"):
+        x = (idx.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed) * np.uint64(0xD1B54A32D192ED03)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return ((x >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)).astype(np.float32)
+
+
+def soup(n, seed=1234, width=1280, height=720, fov=1.9, light=True, materials=None):
+    """Soup(N, seed), SURVEY §8(d): N triangles, centre uniform in [-0.98,0.98]^3 shifted to z=-2.5,
+    vertices = centre + e*U(-1,1)^3 with e = 2*N^(-1/3); 12 draws per triangle in the order centre xyz,
+    a xyz, b xyz, c xyz; flat faces, unshared vertices; one grey diffuse material (0.73) unless a list
+    of materials is given (then triangle i uses material i % len).  Lit by a 4x4 emissive quad at
+    y=+1.5 facing down, L_e=(17,12,4)/pi, outside the cloud.
+    """
+    n = int(n)
+    idx = np.arange(n * 12, dtype=np.uint64)
+    u = (_u01(idx, seed) * np.float32(2.0) - np.float32(1.0)).reshape(n, 12)
+    e = np.float32(2.0 * n ** (-1.0 / 3.0))
+    centre = u[:, 0:3] * np.float32(0.98)
+    centre[:, 2] -= np.float32(2.5)
+    verts = np.empty((n, 3, 3), np.float32)
+    for k in range(3):
+        verts[:, k, :] = centre + e * u[:, 3 + 3 * k:6 + 3 * k]
+    faces = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
+    mats = list(materials) if materials else [diffuse(0.73, 0.73, 0.73)]
+    nm = len(mats)
+    if nm == 1:
+        sets = [(0, np.arange(n, dtype=np.uint32))]
+    else:
+        sets = [(m, np.arange(m, n, nm, dtype=np.uint32)) for m in range(nm)]
+    meshes = [MeshDesc(vertices=verts.reshape(-1, 3), faces=faces, sets=sets)]
+    if light:
+        mats.append(emitter(*LE))
+        meshes.append(_quad((-2.0, 1.5, -0.5), (-2.0, 1.5, -4.5), (2.0, 1.5, -4.5), (2.0, 1.5, -0.5), len(mats) - 1))
+    return SceneDesc(meshes, mats, CameraDesc(width, height, fov), name=f"soup{n}")
+
+
+def closure_zoo():
+    """One material per lobe type of src/bsdf.hpp:14-24 plus mixes, mirroring the constant-input
+    mappings of the BSDF-node shaders: used by the BSDF known-answer tests and
+    the multi-material stand-in scenes."""
+    D, ON, RF, RR, MF, SH, TR = (abi.LOBE_DIFFUSE, abi.LOBE_OREN_NAYAR, abi.LOBE_REFLECTION, abi.LOBE_REFRACTION,
+                                 abi.LOBE_MICROFACET, abi.LOBE_SHEEN, abi.LOBE_TRANSPARENT)
+    return [
+        diffuse(0.73, 0.73, 0.73),                                                          # 0 diffuse_bsdf_node, roughness 0
+        MaterialDesc([LobeDesc(ON, (0.6, 0.5, 0.4), alpha=0.5)]),                           # 1 oren_nayar(N, roughness)
+        MaterialDesc([LobeDesc(RF, (0.9, 0.9, 0.9), eta=0.0)]),                             # 2 glossy sharp -> reflection(N,0)
+        MaterialDesc([LobeDesc(RR, (0.95, 0.95, 0.95), eta=1.45)]),                         # 3 refraction sharp
+        MaterialDesc([LobeDesc(MF, (0.8, 0.7, 0.3), xalpha=0.09, yalpha=0.09)]),            # 4 glossy r=0.3 -> microfacet(r^2)
+        MaterialDesc([LobeDesc(MF, (0.9, 0.9, 0.9), eta=1.33, xalpha=0.2, yalpha=0.2, refract=1)]),  # 5 rough refraction
+        MaterialDesc([LobeDesc(SH, (0.5, 0.2, 0.6), r=0.4)]),                               # 6 sheen
+        MaterialDesc([LobeDesc(TR, (0.8, 0.9, 0.8))]),                                      # 7 transparent
+        MaterialDesc([LobeDesc(D, (0.4, 0.3, 0.2)), LobeDesc(MF, (0.3, 0.3, 0.3), xalpha=0.04, yalpha=0.04)]),  # 8 mix diffuse+glossy
+        MaterialDesc([LobeDesc(D, (0.3, 0.3, 0.5)), LobeDesc(SH, (0.3, 0.3, 0.3), r=0.4), LobeDesc(ON, (0.2, 0.2, 0.2), alpha=0.3)]),  # 9 three lobes
+        MaterialDesc([LobeDesc(RR, (0.6, 0.6, 0.6), eta=1.5), LobeDesc(RF, (0.3, 0.3, 0.3))]),  # 10 glass-like constant mix
+        MaterialDesc([LobeDesc(MF, (0.7, 0.7, 0.7), xalpha=0.25, yalpha=0.0625)]),          # 11 anisotropic glossy
+    ]
+
+
+def multi_material_soup(n, seed=1234, width=1280, height=720):
+    """Declared stand-in for the BMW configs (no scene data ships with the reference):
+    Soup(N) whose triangles cycle through closure_zoo() + 4 more diffuse tints = 16 closure recipes."""
+    mats = closure_zoo() + [diffuse(0.7, 0.2, 0.2), diffuse(0.2, 0.7, 0.2), diffuse(0.2, 0.2, 0.7), diffuse(0.5, 0.5, 0.1)]
+    s = soup(n, seed, width, height, materials=mats)
+    s.name = f"zoo_soup{n}"
+    return s
