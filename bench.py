@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the gfx950 path-tracing device on BASELINE.json's configuration.
+
+A step = one whole frame (xpu_t::start ... join, the reference's own "Rendering time" bracket,
+src/core.cpp:158-177) of the synthetic workload:
+  N=1 : Soup(100k) 1280x720 256 spp, depth 9, pps 1   (BASELINE.json configs[1])
+  N>1 : the same frame, its 32x32 tiles interleaved over the ranks (tile i -> rank i % N), every rank
+        accumulating into its own zero-initialised device film, one RCCL reduce(sum) of the film to
+        rank 0 inside the timed region ("strong" scaling: total work is fixed).
+value = rays traced by ALL ranks (closest-hit + non-masked shadow rays) / max-over-ranks time.
+Scene upload and BVH build (xpu_t::preprocess) happen before the timed region: inputs are HBM-resident.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = k_trace_closest.  achieved = rays * B_ray / kernel time with
+               B_ray = 56 B + V_n*288 B + V_l*384 B (reference layouts); V_n, V_l are
+               measured by the CPU restatement's counters on a tile sample of the same frame; kernel
+               time = sum of HIP-event durations recorded on the device's own stream in the timed steps.
+  cpu_baseline the CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded
+               sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--triangles", type=int, default=100000)
+    p.add_argument("--width", type=int, default=1280)
+    p.add_argument("--height", type=int, default=720)
+    p.add_argument("--spp", type=int, default=256)
+    p.add_argument("--depth", type=int, default=9)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--samples-in-flight", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-tiles", type=int, default=100000, help="tiles of the frame in the CPU baseline sample")
+    p.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel in the CPU baseline sample")
+    p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
+    return p.parse_args()
+
+
+def cpu_baseline(scene, args):
+    """Time the CPU restatement on a bounded sample: `cpu_tiles` tiles spread over the frame x `cpu_spp`
+    samples, counter RNG, all host cores (per-tile parallel, the reference's own threading unit)."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    O = orc.Oracle(scene, spp=args.spp, pps=1, depth=args.depth)
+    all_tiles = []
+    W, H = args.width, args.height
+    for y in range(0, H, 32):
+        for x in range(0, W, 32):
+            all_tiles.append((x, y, min(32, W - x), min(32, H - y)))
+    stride = max(1, len(all_tiles) // max(1, args.cpu_tiles))
+    tiles = all_tiles[::stride][:args.cpu_tiles]
+    _, st = O.render(rng=orc.RNG_COUNTER, seed=args.seed, threads=cores, tiles=tiles, sample_begin=0, sample_end=args.cpu_spp)
+    rays = st["rays_closest"] + st["rays_shadow"]
+    out = {
+        "value": rays / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"{len(tiles)} of {len(all_tiles)} 32x32 tiles x {args.cpu_spp} spp of the same frame, counter RNG, "
+                  f"{rays} rays in {st['seconds']:.2f} s",
+    }
+    vn_c = st["node_visits_closest"] / max(1, st["rays_closest"]); vl_c = st["packet_visits_closest"] / max(1, st["rays_closest"])
+    vn_s = st["node_visits_shadow"] / max(1, st["rays_shadow"]); vl_s = st["packet_visits_shadow"] / max(1, st["rays_shadow"])
+    visits = {"closest": (vn_c, vl_c), "shadow": (vn_s, vl_s), "ref_bvh_nodes": st["bvh_nodes"], "ref_bvh_packets": st["bvh_packets"]}
+    O.close()
+    return out, visits
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or args.force_dist
+    torch = dist = None
+    if use_dist:
+        # torch first: libphx_hip.so then binds to the HIP runtime torch already loaded (one runtime per process)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from phosphorus_mk2_amd import scenes, xpu
+    xpu.load_library()  # raises if the HIP extension is missing: no fallback
+
+    scene = scenes.soup(args.triangles, seed=1234, width=args.width, height=args.height)
+    opts = xpu.Options(samples_per_pixel=args.spp, paths_per_sample=1, path_depth=args.depth,
+                       device_ordinal=local_rank if use_dist else -1, samples_in_flight=args.samples_in_flight)
+    dev = xpu.HipDevice.discover(opts)[0]
+    t0 = time.time()
+    dev.preprocess(scene)  # flatten + BVH build + upload: outside the timed region
+    preprocess_s = time.time() - t0
+    W, H = args.width, args.height
+    tiles = xpu.Tiles.make(W, H, 32, rank, world)
+    film_host = None
+    film_dev = None
+    if use_dist:
+        film_dev = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
+    else:
+        film_host = xpu.Film(W, H, 4)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        tiles.reset()
+        if use_dist:
+            film_dev.zero_()
+            torch.cuda.synchronize()
+            dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
+            dev.join()  # join() synchronises the device's stream
+            dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)  # the single film collective (RCCL over xGMI)
+        else:
+            film_host.data[:] = 0
+            dev.start(scene, xpu.FrameState(args.seed, tiles, film_host))
+            dev.join()
+        return dev.stats()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    acc = {"rays": 0, "closest": 0, "shadow": 0, "closest_ms": 0.0, "shadow_ms": 0.0, "shade_ms": 0.0, "launches": 0, "frame_ms": 0.0}
+    for _ in range(args.steps):
+        st = step()
+        acc["closest"] += st["rays_closest"]; acc["shadow"] += st["rays_shadow"]
+        acc["closest_ms"] += st["closest_ms"]; acc["shadow_ms"] += st["shadow_ms"]; acc["shade_ms"] += st["shade_ms"]
+        acc["launches"] += st["trace_launches"]; acc["frame_ms"] += st["frame_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rays_local = acc["closest"] + acc["shadow"]
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        r = torch.tensor([rays_local], dtype=torch.float64, device="cuda"); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays_total = float(r.item())
+    else:
+        rays_total = float(rays_local)
+
+    if rank == 0:
+        film = film_dev.cpu().numpy() if use_dist else film_host.data
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = rays_total / elapsed / 1e6
+        out = {
+            "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "
+                                   "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
+                       "tiles": "32x32, tile i -> rank i % n_gpus", "film_collective": "reduce(sum) to rank 0" if use_dist else "none",
+                       "rays_per_step": rays_total / args.steps, "camera_samples_per_step": W * H * args.spp,
+                       "preprocess_s": preprocess_s, "bvh_bytes": st["bvh_bytes"], "film_mean": float(film[..., :3].mean()),
+                       "film_finite": bool(np.isfinite(film).all())},
+        }
+        roof = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            base, visits = cpu_baseline(scene, args)
+            out["cpu_baseline"] = base
+            vn, vl = visits["closest"]
+            b_ray = 56.0 + vn * 288.0 + vl * 384.0
+            vns, vls = visits["shadow"]
+            b_shadow = 36.0 + vns * 288.0 + vls * 384.0
+            avg_ms = acc["closest_ms"] / max(1, acc["launches"] // 2)
+            achieved = acc["closest"] * b_ray / (acc["closest_ms"] * 1e-3) / 1e9
+            roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "bytes_per_ray": b_ray,
+                         "visits_per_ray": {"nodes": vn, "leaf_packets": vl}, "launches": acc["launches"] // 2,
+                         "avg_launch_ms": avg_ms, "rays_per_launch": acc["closest"] / max(1, acc["launches"] // 2),
+                         "shadow_kernel": {"bytes_per_ray": b_shadow, "achieved": acc["shadow"] * b_shadow / max(1e-9, acc["shadow_ms"] * 1e-3) / 1e9},
+                         "all_rays_model_frac": (acc["closest"] * b_ray + acc["shadow"] * b_shadow) / elapsed / 1e9 / HBM_PEAK_GBS})
+            out["config"]["gpu_over_cpu"] = value / base["value"]
+        else:
+            out["cpu_baseline"] = None
+        out["roofline"] = roof
+        out["config"]["kernel_ms_per_step"] = {"closest": acc["closest_ms"] / args.steps, "shadow": acc["shadow_ms"] / args.steps,
+                                               "shade_gen_film": acc["shade_ms"] / args.steps, "frame": acc["frame_ms"] / args.steps}
+        print(json.dumps(out))
+    dev.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,399 @@
+// bsdf.h — closure evaluation on the device: the per-hit work of bsdf_t::f (reference
+// src/bsdf.cpp:113-131) and bsdf_t::sample (:133-248) over a baked closure recipe (the output
+// contract of material_t::evaluate, src/material.cpp:218-305, with constant inputs).
+//
+// Lobe models: lambert (src/bsdf/lambert.hpp:8-36), oren-nayar (oren_nayar.hpp:9-69), reflection
+// (reflection.hpp:8-21), refraction (refraction.hpp:10-46), Cook-Torrance GGX reflect/refract
+// (microfacet.hpp:36-278, ggx_t :306-435), sheen (sheen.hpp:16-88), transparent (bsdf.cpp:209-214).
+// The reference's quirks are kept: pdf averaged over matched lobes, f summed;
+// Fresnel eta hard-wired to 0.5 in the reflective microfacet f; G1 evaluated on the world-space wi
+// in its pdf; Lambda's alpha = sqrt(cos^2 phi ax ay + sin^2 phi ax ay); the `/ d * d` precedence
+// slip in the refractive pdf.  Reads of uninitialised memory in the reference (0-lobe bsdf, lobe
+// samplers that return before setting pdf, TIR colour) are defined as "terminate the path".
+//
+// All lobes of a recipe share the hit's shading normal, so the tangent frame
+// (orthogonal_base_t, src/math/orthogonal_base.hpp:11-19) is built once per hit.
+#pragma once
+#include "phx_math.h"
+
+namespace phx {
+
+enum { L_DIFFUSE = 1, L_OREN_NAYAR = 2, L_REFLECTION = 4, L_REFRACTION = 8, L_MICROFACET = 16, L_SHEEN = 32, L_TRANSPARENT = 128 };
+enum { B_DIFFUSE = 1, B_GLOSSY = 2, B_SPECULAR = 4, B_REFLECT = 8, B_TRANSMIT = 16 };
+
+struct DevLobe {       // a lobe after add_lobe()/precompute() (src/bsdf.hpp:54-82, params.hpp)
+  uint32_t type, flags;
+  float wx, wy, wz;    // weight
+  float a, b;          // oren-nayar A, B
+  float eta;
+  float xalpha, yalpha;
+  uint32_t refract;
+  float r;             // sheen roughness
+};
+struct DevMaterial {
+  uint32_t num_lobes;
+  uint32_t is_emitter;
+  float ex, ey, ez;    // hits.e
+  float sheen_L5;      // L(0.5, r) of the first sheen lobe of the material table (sheen.hpp:57 static)
+  uint32_t pad[2];
+  DevLobe lobes[8];
+};
+
+static const double kPiD = 3.14159265358979323846;
+static const double kInvPiD = 0.318309886183790671538;
+
+struct Frame {  // orthogonal_base_t(n) + invertible_base_t::to_local
+  v3 a, b, c;
+  PHX_HD explicit Frame(const v3& n) {
+    a = normalized((n.x != n.y || n.x != n.z) ? v3(n.z - n.y, n.x - n.z, n.y - n.x) : v3(n.z - n.y, n.x + n.z, -n.y - n.x));
+    b = n;
+    c = normalized(cross(a, n));
+  }
+  PHX_HD v3 to_world(const v3& v) const { return v.x * a + v.y * b + v.z * c; }
+  PHX_HD v3 to_local(const v3& v) const { return v.x * v3(a.x, b.x, c.x) + v.y * v3(a.y, b.y, c.y) + v.z * v3(a.z, b.z, c.z); }
+};
+
+namespace ts {  // src/math/vector.hpp:24-72, y is up
+PHX_HD bool same_hemi(const v3& a, const v3& b) { return (a.y * b.y) > 0.0f; }
+PHX_HD float cos2_theta(const v3& v) { return v.y * v.y; }
+PHX_HD float sin2_theta(const v3& v) { return fmaxf(0.0f, 1.0f - v.y * v.y); }
+PHX_HD float sin_theta(const v3& v) { return sqrtf(sin2_theta(v)); }
+PHX_HD float tan_theta(const v3& v) { return sin_theta(v) / v.y; }
+PHX_HD float tan2_theta(const v3& v) { return sin2_theta(v) / cos2_theta(v); }
+PHX_HD float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+PHX_HD float cos_phi(const v3& v) { float s = sin_theta(v); return (s == 0.0f) ? 1.0f : clampf(v.x / s, -1.f, 1.f); }
+PHX_HD float sin_phi(const v3& v) { float s = sin_theta(v); return (s == 0.0f) ? 0.0f : clampf(v.z / s, -1.f, 1.f); }
+}  // namespace ts
+
+PHX_HD void cosine_weighted(float u1, float u2, v3& out, float& pdf) {  // math/sampling.hpp:23-36
+  const float r = sqrtf(u1);
+  const float theta = (float)(2 * kPiD * (double)u2);
+  float s, c; sincosf_(theta, &s, &c);
+  out = v3(r * c, sqrtf(fmaxf(0.0f, 1.0f - u1)), r * s);
+  pdf = out.y * (float)(1.0 / kPiD);
+}
+
+PHX_HD float fresnel_dielectric(float cosi, float eta) {  // math/fresnel.hpp:6-28
+  if (eta == 0.0f) return 1.0f;
+  if (cosi < 0.0f) eta = 1.0f / eta;
+  const float c = fabsf(cosi);
+  float g = eta * eta - 1.0f + c * c;
+  if (g > 0.0f) {
+    g = sqrtf(g);
+    const float A = (g - c) / (g + c);
+    const float B = (c * (g + c) - 1.0f) / (c * (g - c) + 1.0f);
+    return 0.5f * A * A * (1 + B * B);
+  }
+  return 1.0f;
+}
+
+// ---- GGX ---------------------------------------------------------------------------------------
+PHX_HD float ggx_D(const DevLobe& p, const v3& v) {
+  const float tan2 = ts::tan2_theta(v);
+  if (isinf(tan2)) return 0.0f;
+  const float ax = p.xalpha, ay = p.yalpha;
+  const float cos2 = ts::cos2_theta(v);
+  const float cos4 = cos2 * cos2;
+  const float cp = ts::cos_phi(v), sp = ts::sin_phi(v);
+  const float e = ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay)) * tan2;
+  return (float)(1.0f / (kPiD * (double)ax * (double)ay * (double)cos4 * (double)(1 + e) * (double)(1 + e)));
+}
+PHX_HD float ggx_Lambda(const DevLobe& p, const v3& v) {
+  const float att = fabsf(ts::tan_theta(v));
+  if (isinf(att)) return 0.0f;
+  const float ax = p.xalpha, ay = p.yalpha;
+  const float cp = ts::cos_phi(v), sp = ts::sin_phi(v);
+  const float alpha = sqrtf((cp * cp) * ax * ay + (sp * sp) * ax * ay);
+  const float a2t2 = (alpha * att) * (alpha * att);
+  return (-1.0f + sqrtf(1.0f + a2t2)) * 0.5f;
+}
+PHX_HD float ggx_G1(const DevLobe& p, const v3& v) { return 1.0f / (1.0f + ggx_Lambda(p, v)); }
+PHX_HD void ggx_sample_slope(float cos_theta, float& slope_x, float& slope_y, float u, float v) {
+  if ((double)cos_theta > .9999) {
+    const float r = sqrtf(u / (1 - u));
+    const float phi = (float)(6.28318530718 * (double)v);
+    float s, c; sincosf_(phi, &s, &c);
+    slope_x = r * c; slope_y = r * s;
+    return;
+  }
+  const float sin_theta = sqrtf(fmaxf(0.0f, 1.0f - (cos_theta * cos_theta)));
+  const float tan_theta = sin_theta / cos_theta;
+  const float a = 1.0f / tan_theta;
+  const float g1 = 2.0f / (1.0f + sqrtf(1.0f + 1.0f / (a * a)));
+  const float A = 2.0f * u / g1 - 1.0f;
+  float tmp = 1.0f / (A * A - 1.0f);
+  if ((double)tmp > 1e10) tmp = (float)1e10;
+  const float B = tan_theta;
+  const float Dv = sqrtf(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+  const float slope_x1 = B * tmp - Dv;
+  const float slope_x2 = B * tmp + Dv;
+  slope_x = (A < 0.0f || slope_x2 > 1.0f / tan_theta) ? slope_x1 : slope_x2;
+  float S;
+  if (v > 0.5f) { S = 1.0f; v = 2.0f * (v - 0.5f); } else { S = -1.0f; v = 2.0f * (0.5f - v); }
+  const float z = (v * (v * (v * 0.27385f - 0.73369f) + 0.46341f)) / (v * (v * (v * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+  slope_y = S * z * sqrtf(1.0f + slope_x * slope_x);
+}
+PHX_HD v3 ggx_sample(const DevLobe& p, const v3& wi, float& pdf, float u, float v) {
+  const float ax = p.xalpha, ay = p.yalpha;
+  const v3 stretched = normalize_inplace(v3(ax * wi.x, wi.y, ay * wi.z));
+  float slope_x, slope_y;
+  ggx_sample_slope(stretched.y, slope_x, slope_y, u, v);
+  const float cp = ts::cos_phi(stretched), sp = ts::sin_phi(stretched);
+  const float tmp = cp * slope_x - sp * slope_y;
+  slope_y = sp * slope_x + cp * slope_y;
+  slope_x = tmp;
+  slope_x = slope_x * ax;
+  slope_y = slope_y * ay;
+  const v3 wh = normalize_inplace(v3(-slope_x, 1.0f, -slope_y));
+  pdf = (ggx_D(p, wh) * ggx_G1(p, wi) * fabsf(dot(wi, wh)) / fabsf(wi.y));
+  return wh;
+}
+
+// ---- sheen distribution ----------------------------------------------------------------------------
+PHX_HD float sheen_L(float x, float r) {
+  const float t = (1.0f - r) * (1.0f - r);
+  const float a = t * 25.3245f + (1.0f - t) * 21.5473f;
+  const float b = t * 3.32435f + (1.0f - t) * 3.82987f;
+  const float c = t * 0.16801f + (1.0f - t) * 0.19823f;
+  const float d = t * -1.27393f + (1.0f - t) * -1.97760f;
+  const float e = t * -4.85967f + (1.0f - t) * -4.32054f;
+  const float xc = powf_(x, c);
+  return a / (1 + b * xc) + d * x + e;
+}
+PHX_HD float sheen_D(const DevLobe& p, const v3& v) {
+  const float st = ts::sin_theta(v);
+  const float oor = 1.0f / p.r;
+  return (float)((double)((2.0f + oor) * powf_(st, oor)) / (2.0f * kPiD));
+}
+PHX_HD float sheen_Lambda(const DevLobe& p, const v3& v, float L5) {
+  const float ct = v.y;
+  const float l = (ct < 0.5f) ? sheen_L(ct, p.r) : 2.0f * L5 - sheen_L(1.0f - ct, p.r);
+  return expf_(l);
+}
+
+// ---- Cook-Torrance (local-space inputs; SHEEN selects the distribution) -----------------------------
+template <bool SHEEN>
+PHX_HD float ct_f_local(const DevLobe& p, const v3& li, const v3& lo, float L5) {
+  if (!ts::same_hemi(li, lo)) return 0.0f;
+  v3 wh = li + lo;
+  const float cos_ti = fabsf(li.y), cos_to = fabsf(lo.y);
+  if (cos_ti == 0.0f || cos_to == 0.0f) return 0.0f;
+  if (wh.x == 0.0f || wh.y == 0.0f || wh.z == 0.0f) return 0.0f;
+  wh = normalize_inplace(wh);
+  const float d = SHEEN ? sheen_D(p, wh) : ggx_D(p, wh);
+  const float lam_i = SHEEN ? sheen_Lambda(p, li, L5) : ggx_Lambda(p, li);
+  const float lam_o = SHEEN ? sheen_Lambda(p, lo, L5) : ggx_Lambda(p, lo);
+  const float g = 1.0f / (1.0f + lam_i + lam_o);
+  const float whdoty = wh.x * 0.0f + wh.y * 1.0f + wh.z * 0.0f;
+  const v3 whf = whdoty < 0.0f ? -wh : wh;
+  const float f = fresnel_dielectric(dot(lo, whf), 0.5f);
+  return d * g * f * (1.0f / (4.0f * cos_ti * cos_to));
+}
+PHX_HD float ct_pdf(const DevLobe& p, const v3& wi_world, const v3& li, const v3& lo) {
+  if (!ts::same_hemi(li, lo)) return 0.0f;
+  const v3 wh = normalize_inplace(li + lo);
+  return (ggx_D(p, wh) * ggx_G1(p, wi_world) * fabsf(dot(li, wh)) / fabsf(li.y)) / (4.0f * dot(li, wh));
+}
+PHX_HD float ctr_f_local(const DevLobe& p, const v3& li, const v3& lo) {
+  if (ts::same_hemi(li, lo)) return 0.0f;
+  const float eta = li.y > 0.0f ? p.eta : 1.0f / p.eta;
+  const float cos_ti = li.y, cos_to = lo.y;
+  if (cos_ti == 0.0f || cos_to == 0.0f) return 0.0f;
+  v3 wh = normalize_inplace(li + lo * eta);
+  if (wh.y < 0.0f) wh = -wh;
+  if (dot(lo, wh) * dot(li, wh) > 0.0f) return 0.0f;
+  const float f = fresnel_dielectric(dot(lo, wh), eta);
+  const float sqrt_denom = dot(li, wh) + eta * dot(lo, wh);
+  const float factor = 1.0f / eta;
+  const float d = ggx_D(p, wh);
+  const float g = 1.0f / (1.0f + ggx_Lambda(p, li) + ggx_Lambda(p, lo));
+  return (1.0f - f) * fabsf(d * g * eta * eta * fabsf(dot(lo, wh)) * fabsf(dot(li, wh)) * factor * factor /
+                            (cos_ti * cos_to * sqrt_denom * sqrt_denom));
+}
+PHX_HD float ctr_pdf(const DevLobe& p, const v3& wi_world, const v3& wo_world, const v3& li, const v3& lo) {
+  const float eta = li.y > 0.0f ? p.eta : 1.0f / p.eta;
+  if ((double)dot(wo_world, wi_world) > 0.0) return 0.0f;
+  const v3 wh = normalize_inplace(li + lo * eta);
+  const float sqrt_denom = dot(li, wh) + eta * dot(lo, wh);
+  const float dwh_dwi = fabsf(eta * eta * dot(lo, wh)) / sqrt_denom * sqrt_denom;
+  return (ggx_D(p, wh) * wh.y) * dwh_dwi;
+}
+PHX_HD float oren_nayar_f_local(const DevLobe& p, const v3& li, const v3& lo) {
+  const float cos_theta_i = fabsf(li.y), cos_theta_o = fabsf(lo.y);
+  const float sin_theta_i = ts::sin_theta(li), sin_theta_o = ts::sin_theta(lo);
+  float max_cos = 0.0f;
+  if (sin_theta_i > 0.0001f && sin_theta_o > 0.0001f) {
+    const float sin_phi_i = ts::sin_phi(li), cos_phi_i = ts::cos_phi(li);
+    const float sin_phi_o = ts::sin_phi(lo), cos_phi_o = ts::cos_phi(lo);
+    const float dcos = cos_phi_i * cos_phi_o + sin_phi_i * sin_phi_o;
+    max_cos = fmaxf(0.0f, dcos);
+  }
+  float sin_alpha, tan_beta;
+  if (cos_theta_i > cos_theta_o) { sin_alpha = sin_theta_o; tan_beta = sin_theta_i / cos_theta_i; }
+  else { sin_alpha = sin_theta_i; tan_beta = sin_theta_o / cos_theta_o; }
+  const float result = (p.a + p.b * max_cos * sin_alpha * tan_beta);
+  return (float)((double)result * kInvPiD);
+}
+
+// eval() of src/bsdf.cpp:29-107: value (grey) and pdf of lobe p for the world-space pair (wi, wo)
+PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3& wi, const v3& wo, float L5, float& pdf) {
+  switch (p.type) {
+    case L_DIFFUSE:
+      pdf = (float)((double)dot(n, wi) * kInvPiD);
+      return (float)kInvPiD;
+    case L_OREN_NAYAR:
+      pdf = (float)((double)dot(n, wi) * kInvPiD);
+      return oren_nayar_f_local(p, fr.to_local(wi), fr.to_local(wo));
+    case L_MICROFACET: {
+      const v3 li = fr.to_local(wi), lo = fr.to_local(wo);
+      if (p.refract) { pdf = ctr_pdf(p, wi, wo, li, lo); return ctr_f_local(p, li, lo); }
+      pdf = ct_pdf(p, wi, li, lo);
+      return ct_f_local<false>(p, li, lo, L5);
+    }
+    case L_SHEEN:
+      pdf = (float)((double)dot(n, wi) * kInvPiD);
+      return ct_f_local<true>(p, fr.to_local(wi), fr.to_local(wo), L5);
+    default:  // reflection, refraction, transparent: delta lobes
+      pdf = 0.0f;
+      return 0.0f;
+  }
+}
+
+// bsdf_t::f, src/bsdf.cpp:113-131
+PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) {
+  v3 out(0.0f);
+  if (m.num_lobes == 0) return out;
+  const Frame fr(n);
+  const float atl = dot(n, wi);
+  const bool reflect = atl * dot(n, wo) > 0.0f;
+  for (uint32_t i = 0; i < m.num_lobes; ++i) {
+    const DevLobe& p = m.lobes[i];
+    float ignored;
+    const float e = lobe_eval(p, n, fr, wi, wo, m.sheen_L5, ignored);
+    if ((reflect && (p.flags & B_REFLECT)) || (!reflect && (p.flags & B_TRANSMIT))) {
+      const v3 ew = v3(e) * v3(p.wx, p.wy, p.wz);
+      out = out + ew * atl;
+    }
+  }
+  return out;
+}
+
+// bsdf_t::sample, src/bsdf.cpp:133-248.  Returns f (already weighted); pdf == 0 terminates.
+PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
+  pdf = 0.0f; sample_flags = 0; wo = v3(0.0f);
+  const uint32_t lobes = m.num_lobes;
+  if (lobes == 0) return v3(0.0f);
+  const float fl = (float)lobes;
+  uint32_t index = (uint32_t)floorf(u1 * fl);
+  if (index > lobes - 1) index = lobes - 1;
+  const float one_minus_epsilon = 1.0f - FLT_EPSILON;
+  const float u = fminf(u1 * fl - (float)index, one_minus_epsilon);
+  const DevLobe& p = m.lobes[index];
+  const Frame fr(n);
+  float res = 0.0f;
+  bool pdf_set = false;
+  switch (p.type) {
+    case L_DIFFUSE: {
+      v3 l; cosine_weighted(u, u2, l, pdf); pdf_set = true;
+      wo = fr.to_world(l);
+      res = (float)kInvPiD;
+      break;
+    }
+    case L_OREN_NAYAR: {
+      v3 l; cosine_weighted(u, u2, l, pdf); pdf_set = true;
+      wo = fr.to_world(l);
+      res = oren_nayar_f_local(p, fr.to_local(wi), fr.to_local(wo));
+      break;
+    }
+    case L_SHEEN: {
+      v3 l; cosine_weighted(u, u2, l, pdf); pdf_set = true;
+      wo = fr.to_world(l);
+      res = ct_f_local<true>(p, fr.to_local(wi), fr.to_local(wo), m.sheen_L5);
+      break;
+    }
+    case L_MICROFACET: {
+      if (p.refract) {  // microfacet.hpp:118-171
+        if (p.eta == 1.0f) { wo = -wi; pdf = 1.0f; pdf_set = true; res = 1.0f; break; }
+        const v3 li = fr.to_local(wi);
+        if (li.y == 0.0f) break;
+        float dpdf;
+        const v3 wh = ggx_sample(p, li, dpdf, u, u2);
+        if (dot(wh, li) < 0.0f) break;
+        const float eta = li.y > 0.0f ? 1.0f / p.eta : p.eta;
+        const float cos_ti = dot(wh, li);
+        const float sin2_ti = fmaxf(0.0f, 1.0f - cos_ti * cos_ti);
+        const float sin2_tt = eta * eta * sin2_ti;
+        if (sin2_tt >= 1.0f) break;
+        const float cos_tt = sqrtf(1.0f - sin2_tt);
+        const v3 lo = eta * -li + (eta * cos_ti - cos_tt) * wh;
+        const float sqrt_denom = dot(li, wh) + eta * dot(lo, wh);
+        const float dwh_dwi = fabsf((eta * eta * dot(lo, wh)) / (sqrt_denom * sqrt_denom));
+        pdf = dpdf * dwh_dwi; pdf_set = true;
+        wo = fr.to_world(lo);
+        res = ctr_f_local(p, fr.to_local(wi), fr.to_local(wo));
+      } else {  // microfacet.hpp:237-277
+        const v3 li = fr.to_local(wi);
+        if (li.y == 0.0f) break;
+        float dpdf;
+        const v3 wh = ggx_sample(p, li, dpdf, u, u2);
+        if (dot(li, wh) < 0.0f) break;
+        const v3 lo = -li + (2.0f * dot(li, wh)) * wh;
+        if (!ts::same_hemi(li, lo)) break;
+        pdf = dpdf / (4.0f * dot(li, wh)); pdf_set = true;
+        wo = fr.to_world(lo);
+        res = ct_f_local<false>(p, fr.to_local(wi), fr.to_local(wo), m.sheen_L5);
+      }
+      break;
+    }
+    case L_REFLECTION: {
+      const float cos_theta = dot(n, wi);
+      pdf = 1.0f; pdf_set = true;
+      wo = -wi + (2.0f * cos_theta) * n;
+      res = 1.0f;
+      break;
+    }
+    case L_REFRACTION: {
+      pdf = 1.0f; pdf_set = true;
+      float cos_theta = dot(n, wi);
+      const float sin_theta = fmaxf(0.0f, 1.0f - cos_theta * cos_theta);
+      v3 nn; float eta = p.eta;
+      if (cos_theta > 0.0f) { nn = n; eta = 1.0f / eta; } else { nn = -n; cos_theta = -cos_theta; }
+      const float arg = 1.0f - (eta * eta * sin_theta);
+      if (arg >= 0.0f) {
+        const float dnp = sqrtf(arg);
+        const float nk = eta * cos_theta - dnp;
+        wo = -wi * eta + nn * nk;
+        res = 1.0f;
+      } else {
+        res = 0.0f;  // TIR: defined as black
+      }
+      break;
+    }
+    case L_TRANSPARENT:
+      wo = -wi; pdf = 1.0f; pdf_set = true; res = 1.0f;
+      break;
+    default: break;
+  }
+  if (!pdf_set) pdf = 0.0f;
+  if (pdf == 0.0f) return v3(0.0f);
+  v3 result = v3(res) * v3(p.wx, p.wy, p.wz);
+  int matched = 1;
+  for (uint32_t i = 0; i < lobes; ++i) {
+    const DevLobe& q = m.lobes[i];
+    if (i != index && ((p.flags & q.flags) == q.flags)) {
+      const bool reflect = dot(n, wi) * dot(n, wo) > 0.0f;
+      if ((reflect && (q.flags & B_REFLECT)) || (!reflect && (q.flags & B_TRANSMIT))) {
+        float lobe_pdf = 0.0f;
+        const float e = lobe_eval(q, n, fr, wi, wo, m.sheen_L5, lobe_pdf);
+        result = result + v3(e) * v3(q.wx, q.wy, q.wz);
+        pdf += lobe_pdf;
+        ++matched;
+      }
+    }
+  }
+  pdf /= (float)matched;
+  sample_flags = p.flags;
+  return result;
+}
+
+}  // namespace phx

@@ -1,0 +1,184 @@
+// bvh8.h — the device's acceleration structure: an 8-wide BVH with 80-byte quantised nodes
+// ("nodelets": five 16-B words, child boxes as 8-bit grid coordinates relative to the node's own
+// box) and 48-byte Moeller-Trumbore triangle records (v0, e0, e1, primitive id).  It takes the
+// place of accel::mbvh_t (reference src/accel/bvh.hpp:17-49: 288-B nodes, 384-B packets) and of
+// the stream traversal in src/kernels/cpu/stream_bvh_kernel.cpp:18-148, redesigned for one ray
+// per lane on a 64-lane wavefront:
+//   * children are stored in "octant order" slots so the visiting order comes from the ray's sign
+//     bits alone — no per-lane distance sort, no per-child ray lists (the MBVH-RS lanes_t),
+//   * one stack entry is a (base, hit-bitmask) group, so the per-lane stack is <= tree depth,
+//   * the box test is conservative (boxes are quantised outwards, both slab ends padded), hence
+//     the set of triangles a ray is tested against always contains every triangle it can hit and
+//     the closest hit is independent of tree topology; the triangle test itself is the reference's
+//     arithmetic (src/accel/triangle.hpp:149-164: FMA cross/dot, true division, eps 1e-8,
+//     u>=0, v>=0, u+v<=1, 0<=t<tmax) evaluated per lane.
+#pragma once
+#include "phx_math.h"
+
+namespace phx {
+
+struct alignas(16) Node8 {
+  float px, py, pz;           // origin of the quantisation grid (node box min)
+  uint8_t ex, ey, ez, imask;  // grid scale exponents (biased like fp32), bit i of imask: child slot i is an inner node
+  uint32_t child_base;        // index of this node's first inner child (children are contiguous, in slot order)
+  uint32_t tri_base;          // index of this node's first triangle record
+  uint8_t meta[8];            // inner: 0b001_11sss (24+slot); leaf: unary count <<5 | first triangle offset; empty: 0
+  uint8_t qlox[8], qloy[8], qloz[8], qhix[8], qhiy[8], qhiz[8];
+};
+static_assert(sizeof(Node8) == 80, "Node8 must be five 16-byte words");
+
+struct TriRec {  // 48 B: three 16-byte words
+  float v0x, v0y, v0z, e0x;
+  float e0y, e0z, e1x, e1y;
+  float e1z;
+  uint32_t prim;  // index in scene_t::triangles() order
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be three 16-byte words");
+
+struct Hit { float t, u, v; uint32_t tri; };  // tri = index of the TriRec, 0xffffffff = miss
+
+PHX_HD int clz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clz((int)x);
+#else
+  return x ? __builtin_clz(x) : 32;
+#endif
+}
+PHX_HD int popc32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popc(x);
+#else
+  return __builtin_popcount(x);
+#endif
+}
+PHX_HD float u32_as_f32(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+
+// Reference Moeller-Trumbore (src/accel/triangle.hpp:149-164) for one ray and one triangle.
+PHX_HD bool mt_intersect(const TriRec& T, const v3& o, const v3& wi, float tmax, float& us, float& vs, float& ds) {
+  const v3 e0(T.e0x, T.e0y, T.e0z), e1(T.e1x, T.e1y, T.e1z), v0(T.v0x, T.v0y, T.v0z);
+  const v3 t = o - v0;
+  const v3 p = scross(wi, e1);
+  const float det = sdot(e0, p);
+  const float ood = 1.0f / det;
+  const v3 q = scross(t, e0);
+  us = sdot(t, p) * ood;
+  vs = sdot(wi, q) * ood;
+  ds = sdot(e1, q) * ood;
+  const bool xmask = (det > 0.00000001f) || (det < -0.00000001f);
+  const bool umask = us >= 0.0f;
+  const bool vmask = (vs >= 0.0f) && ((us + vs) <= 1.0f);
+  const bool dmask = (ds >= 0.0f) && (ds < tmax);
+  return vmask && umask && dmask && xmask;
+}
+
+// The 8 box tests of one node for one ray.  Returns the CWBVH-style hit mask: inner children set
+// bit 24 + (slot ^ oct_inv), the triangles of a hit leaf child set their bits in [0,24).
+struct RayCtx {
+  v3 o, d;
+  float idx, idy, idz;   // clamped reciprocal direction
+  uint32_t oct_inv;      // (dx>=0?4:0)|(dy>=0?2:0)|(dz>=0?1:0)
+};
+PHX_HD RayCtx make_ray_ctx(const v3& o, const v3& d) {
+  RayCtx r; r.o = o; r.d = d;
+  const float big = 1e20f, tiny = 1e-20f;
+  r.idx = fabsf(d.x) > tiny ? 1.0f / d.x : (d.x < 0.0f ? -big : big);
+  r.idy = fabsf(d.y) > tiny ? 1.0f / d.y : (d.y < 0.0f ? -big : big);
+  r.idz = fabsf(d.z) > tiny ? 1.0f / d.z : (d.z < 0.0f ? -big : big);
+  r.oct_inv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+  return r;
+}
+
+PHX_HD uint32_t node_hitmask(const uint32_t* w /* 20 words of the node */, const RayCtx& r, float tmax) {
+  const float px = u32_as_f32(w[0]), py = u32_as_f32(w[1]), pz = u32_as_f32(w[2]);
+  const uint32_t e = w[3];
+  const float sx = u32_as_f32((e & 0xffu) << 23), sy = u32_as_f32(((e >> 8) & 0xffu) << 23), sz = u32_as_f32(((e >> 16) & 0xffu) << 23);
+  const float ax = sx * r.idx, ay = sy * r.idy, az = sz * r.idz;
+  const float bx = (px - r.o.x) * r.idx, by = (py - r.o.y) * r.idy, bz = (pz - r.o.z) * r.idz;
+  const bool nx = r.idx < 0.0f, ny = r.idy < 0.0f, nz = r.idz < 0.0f;
+  // words: 6,7 meta | 8,9 qlox | 10,11 qloy | 12,13 qloz | 14,15 qhix | 16,17 qhiy | 18,19 qhiz
+  uint32_t hitmask = 0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const uint32_t meta4 = w[6 + half];
+    const uint32_t nearx = nx ? w[14 + half] : w[8 + half], farx = nx ? w[8 + half] : w[14 + half];
+    const uint32_t neary = ny ? w[16 + half] : w[10 + half], fary = ny ? w[10 + half] : w[16 + half];
+    const uint32_t nearz = nz ? w[18 + half] : w[12 + half], farz = nz ? w[12 + half] : w[18 + half];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sh = 8 * j;
+      const float tnx = fmaf((float)((nearx >> sh) & 0xffu), ax, bx);
+      const float tny = fmaf((float)((neary >> sh) & 0xffu), ay, by);
+      const float tnz = fmaf((float)((nearz >> sh) & 0xffu), az, bz);
+      const float tfx = fmaf((float)((farx >> sh) & 0xffu), ax, bx);
+      const float tfy = fmaf((float)((fary >> sh) & 0xffu), ay, by);
+      const float tfz = fmaf((float)((farz >> sh) & 0xffu), az, bz);
+      float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+      float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+      tn = tn - fabsf(tn) * 4.76837158203125e-7f;  // pad both ends by 4 ulp: never reject a box that holds a hit
+      tf = tf + fabsf(tf) * 4.76837158203125e-7f;
+      const uint32_t meta = (meta4 >> sh) & 0xffu;
+      if (tn <= tf) {
+        const uint32_t is_inner = ((meta & 0x18u) == 0x18u) ? 7u : 0u;
+        const uint32_t bit_index = (meta & 31u) ^ (r.oct_inv & is_inner);
+        hitmask |= (meta >> 5) << bit_index;
+      }
+    }
+  }
+  return hitmask;
+}
+
+// Closest-hit (ANY=false) or any-hit (ANY=true) traversal of one ray.  Stack: push(uint32,uint32),
+// pop(uint32&,uint32&), empty().  Counters are optional (host-side validation only).
+template <bool ANY, typename Stack>
+PHX_HD bool traverse8(const uint32_t* __restrict__ nodes /* 20 words per node */, const TriRec* __restrict__ tris,
+                      const v3& o, const v3& d, float tmax, Hit& hit, Stack& stack,
+                      uint32_t* node_visits = nullptr, uint32_t* tri_tests = nullptr) {
+  const RayCtx r = make_ray_ctx(o, d);
+  hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xffffffffu;
+  uint32_t ng_base = 0, ng_hits = 0x80000000u;  // the root as a one-child group
+  for (;;) {
+    // visit the nearest not-yet-visited inner child of the current group
+    const uint32_t bit = 31u - (uint32_t)clz32(ng_hits);
+    const uint32_t rest = ng_hits & ~(1u << bit);
+    if (rest > 0x00ffffffu) stack.push(ng_base, rest);
+    const uint32_t slot = (bit - 24u) ^ r.oct_inv;
+    const uint32_t rel = (uint32_t)popc32(ng_hits & 0xffu & ~(0xffffffffu << slot));
+    const uint32_t ni = ng_base + rel;
+    uint32_t w[20];
+    {
+      const uint32_t* src = nodes + (size_t)ni * 20u;
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint4* s4 = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { uint4 q = s4[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+#else
+      for (int k = 0; k < 20; ++k) w[k] = src[k];
+#endif
+    }
+    if (node_visits) ++*node_visits;
+    const uint32_t hm = node_hitmask(w, r, hit.t);
+    ng_base = w[4];
+    ng_hits = (hm & 0xff000000u) | (w[3] >> 24);
+    uint32_t th = hm & 0x00ffffffu;
+    const uint32_t tb = w[5];
+    while (th) {
+      const uint32_t k = 31u - (uint32_t)clz32(th);
+      th &= ~(1u << k);
+      const TriRec T = tris[tb + k];
+      float us, vs, ds;
+      if (tri_tests) ++*tri_tests;
+      if (mt_intersect(T, o, d, hit.t, us, vs, ds)) {
+        hit.t = ds; hit.u = us; hit.v = vs; hit.tri = tb + k;
+        if (ANY) return true;
+      }
+    }
+    if (ng_hits <= 0x00ffffffu) {
+      if (stack.empty()) break;
+      stack.pop(ng_base, ng_hits);
+    }
+  }
+  return hit.tri != 0xffffffffu;
+}
+
+}  // namespace phx

@@ -1,0 +1,603 @@
+// device.cpp — host side of the gfx950 device: the C ABI of include/phx_xpu.h.
+//
+// Mirrors cpu_t (reference src/xpu/cpu.cpp:208-248): preprocess() flattens the scene and builds the
+// accelerator (cpu.cpp:35-44), start() spawns a driver thread that drains the shared tile queue
+// (cpu.cpp:223-238) — in batches of many tiles, each carried through the wavefront kernels of
+// kernels.hip — and hands finished tiles to the film sink (cpu.cpp:201), join() waits for it.
+// There is no CPU rendering path in this library: without a gfx950 device every entry point fails.
+#include "../../include/phx_xpu.h"
+#include "bvh_build.h"
+#include "kernels.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace phx;
+
+namespace {
+
+thread_local std::string g_error;
+std::string g_error_shared;  // last error of any driver thread (read by phx_last_error after join)
+
+int fail(int code, const std::string& msg) { g_error = msg; g_error_shared = msg; return code; }
+
+#define HIPCHK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return fail(PHX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  int alloc(size_t count) {
+    if (count <= n && p) return PHX_OK;
+    release();
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return fail(PHX_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    n = count;
+    return PHX_OK;
+  }
+  int upload(const std::vector<T>& h) {
+    int rc = alloc(h.size()); if (rc) return rc;
+    if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PHX_OK;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct phx_tiles {
+  std::vector<phx_tile> tiles;
+  std::atomic<uint32_t> cursor{0};
+};
+
+struct phx_device {
+  phx_options opt{};
+  int hip_device = 0;
+  hipStream_t stream = nullptr;
+  bool preprocessed = false;
+
+  // scene
+  DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals;
+  DevBuf<DevMaterial> d_materials; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
+  DevScene scene{};
+  uint32_t num_materials = 0;
+  uint64_t bvh_nodes = 0, bvh_bytes = 0, num_triangles = 0;
+
+  // pass buffers
+  DevBuf<float4> ro[2], rd[2], hit, so, sd, sc, pb, pr, pn;
+  DevBuf<uint32_t> counters; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
+  float* h_acc = nullptr; size_t h_acc_n = 0;  // pinned staging for add_tile
+
+  // frame
+  phx_frame frame{};
+  std::thread driver;
+  bool running = false;
+  int frame_status = PHX_OK;
+  phx_stats stats{};
+  std::vector<hipEvent_t> events; size_t events_used = 0;
+  std::vector<std::pair<size_t, int>> timed;  // (event index of start, kind 0 closest / 1 shadow / 2 other)
+
+  ~phx_device() {
+    if (driver.joinable()) driver.join();
+    for (auto e : events) (void)hipEventDestroy(e);
+    if (h_acc) (void)hipHostFree(h_acc);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int next_event(hipEvent_t* out) {
+    if (events_used == events.size()) {
+      hipEvent_t e; HIPCHK(hipEventCreate(&e));
+      events.push_back(e);
+    }
+    *out = events[events_used++];
+    return PHX_OK;
+  }
+  int run_frame();
+  int render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit);
+};
+
+// ---- scene flattening --------------------------------------------------------------------------------
+namespace {
+
+// microfacet_t::roughness_to_alpha + precompute (src/bsdf/params.hpp:86-99), with the device's logf_
+float roughness_to_alpha(float roughness) {
+  roughness = std::max(roughness, (float)1e-5);
+  float x = logf_(roughness);
+  return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+
+int bake_material(const phx_material& m, float sheen_L5, DevMaterial& out) {
+  std::memset(&out, 0, sizeof(out));
+  out.is_emitter = m.is_emitter; out.ex = m.emission[0]; out.ey = m.emission[1]; out.ez = m.emission[2];
+  out.sheen_L5 = sheen_L5;
+  if (m.num_lobes > PHX_MAX_LOBES) return 1;
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < m.num_lobes; ++i) {
+    const phx_lobe& s = m.lobes[i];
+    DevLobe& l = out.lobes[k];
+    l.type = s.type; l.wx = s.weight[0]; l.wy = s.weight[1]; l.wz = s.weight[2];
+    switch (s.type) {
+      case PHX_LOBE_DIFFUSE: l.flags = B_REFLECT | B_DIFFUSE; break;
+      case PHX_LOBE_OREN_NAYAR: {  // oren_nayar_t::precompute, params.hpp:36-43
+        l.flags = B_REFLECT | B_DIFFUSE;
+        const float sg = (float)((double)s.alpha * (kPiD / (double)180.0f));
+        const float s2 = sg * sg;
+        l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+        l.b = 0.45f * s2 / (s2 + 0.09f);
+        break;
+      }
+      case PHX_LOBE_REFLECTION: l.flags = B_REFLECT | B_SPECULAR; l.eta = s.eta; break;
+      case PHX_LOBE_REFRACTION: l.flags = B_TRANSMIT | B_SPECULAR; l.eta = s.eta; break;
+      case PHX_LOBE_MICROFACET:
+        l.flags = s.refract ? B_TRANSMIT : B_REFLECT;  // src/bsdf.hpp:70-72
+        l.eta = s.eta; l.refract = s.refract;
+        l.xalpha = std::min(1.0f, std::max(0.0001f, roughness_to_alpha(s.xalpha)));
+        l.yalpha = std::min(1.0f, std::max(0.0001f, roughness_to_alpha(s.yalpha)));
+        break;
+      case PHX_LOBE_SHEEN: l.flags = B_REFLECT | B_GLOSSY; l.r = s.r; break;
+      case PHX_LOBE_TRANSPARENT: l.flags = B_TRANSMIT; break;  // src/material.cpp:98-103
+      case PHX_LOBE_EMISSIVE: case PHX_LOBE_BACKGROUND: continue;  // not lobes (material.cpp:240-245)
+      default: return 1;
+    }
+    ++k;
+  }
+  out.num_lobes = k;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* phx_last_error(void) { return g_error.empty() ? g_error_shared.c_str() : g_error.c_str(); }
+
+int phx_discover(const phx_options* options, int* num_devices) {
+  if (!num_devices) return fail(PHX_ERR_ARG, "phx_discover: null out pointer");
+  *num_devices = 0;
+  if (options && options->host_only) return PHX_OK;  // --no-gpu (src/core.cpp:49-52)
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(PHX_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  int usable = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  *num_devices = usable;
+  if (!usable) return fail(PHX_ERR_NO_DEVICE, "no gfx950 (MI355X) device visible");
+  return PHX_OK;
+}
+
+phx_device* phx_dev_make(const phx_options* options) {
+  if (!options) { fail(PHX_ERR_ARG, "phx_dev_make: null options"); return nullptr; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); fail(PHX_ERR_NO_DEVICE, "no HIP device: the gfx950 path cannot run"); return nullptr; }
+  int dev = options->device_ordinal;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= n) { fail(PHX_ERR_ARG, "device_ordinal out of range"); return nullptr; }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess || std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+    fail(PHX_ERR_NO_DEVICE, std::string("device is not gfx950: ") + p.gcnArchName);
+    return nullptr;
+  }
+  if (hipSetDevice(dev) != hipSuccess) { fail(PHX_ERR_DEVICE, "hipSetDevice failed"); return nullptr; }
+  phx_device* d = new phx_device();
+  d->opt = *options; d->hip_device = dev;
+  if (d->opt.samples_per_pixel == 0) d->opt.samples_per_pixel = 16;
+  if (d->opt.paths_per_sample == 0) d->opt.paths_per_sample = 1;
+  if (d->opt.path_depth == 0) d->opt.path_depth = 9;
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { delete d; fail(PHX_ERR_DEVICE, "hipStreamCreate failed"); return nullptr; }
+  return d;
+}
+
+void phx_dev_destroy(phx_device* dev) {
+  if (!dev) return;
+  (void)hipSetDevice(dev->hip_device);
+  delete dev;
+}
+
+int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
+  if (!d || !s) return fail(PHX_ERR_ARG, "preprocess: null argument");
+  if (d->running) return fail(PHX_ERR_STATE, "preprocess while a frame is running");
+  if (!s->meshes || !s->materials || s->num_materials == 0) return fail(PHX_ERR_ARG, "scene without meshes/materials");
+  if (s->camera.aperture_radius != 0.0f) return fail(PHX_ERR_ARG, "thin-lens cameras are not supported (reference path is broken, SURVEY A-21)");
+  if (s->camera.film_width == 0 || s->camera.film_height == 0 || s->camera.film_width > 65535 || s->camera.film_height > 65535)
+    return fail(PHX_ERR_ARG, "film size out of range");
+  if (s->environment_material >= (int32_t)s->num_materials) return fail(PHX_ERR_ARG, "environment material out of range");
+  HIPCHK(hipSetDevice(d->hip_device));
+
+  // triangles in scene_t::triangles() order: mesh order x face-set order (scene.cpp:58-62, mesh.cpp:118-128)
+  std::vector<float> abc; std::vector<uint32_t> prim_material; std::vector<float> prim_normals;
+  std::vector<DevLight> lights; std::vector<DevLightTri> light_tris;
+  bool any_smooth = false;
+  for (uint32_t mi = 0; mi < s->num_meshes; ++mi) {
+    const phx_mesh& m = s->meshes[mi];
+    for (uint32_t f = 0; f < m.num_faces; ++f) if (m.smooth && m.smooth[f]) any_smooth = true;
+  }
+  for (uint32_t mi = 0; mi < s->num_meshes; ++mi) {
+    const phx_mesh& m = s->meshes[mi];
+    if (!m.vertices || !m.faces || (m.num_sets && !m.sets)) return fail(PHX_ERR_ARG, "mesh with null arrays");
+    for (uint32_t si = 0; si < m.num_sets; ++si) {
+      const phx_face_set& fs = m.sets[si];
+      if (fs.material >= s->num_materials) return fail(PHX_ERR_ARG, "face set material out of range");
+      const bool emitter = s->materials[fs.material].is_emitter != 0;
+      DevLight L{(uint32_t)light_tris.size(), 0, 0.0f, fs.material};
+      for (uint32_t k = 0; k < fs.num_faces; ++k) {
+        const uint32_t f = fs.faces[k];
+        if (f >= m.num_faces) return fail(PHX_ERR_ARG, "face index out of range");
+        const uint32_t ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
+        if (ia >= m.num_vertices || ib >= m.num_vertices || ic >= m.num_vertices) return fail(PHX_ERR_ARG, "vertex index out of range");
+        const uint32_t prim = (uint32_t)prim_material.size();
+        const float* a = m.vertices + 3 * (size_t)ia; const float* b = m.vertices + 3 * (size_t)ib; const float* c = m.vertices + 3 * (size_t)ic;
+        abc.insert(abc.end(), a, a + 3); abc.insert(abc.end(), b, b + 3); abc.insert(abc.end(), c, c + 3);
+        const bool smooth = m.smooth && m.smooth[f];
+        prim_material.push_back(fs.material | (smooth ? 0x80000000u : 0u));
+        if (any_smooth) {
+          uint32_t na = ia, nb = ib, nc = ic;
+          if (!(m.flags & PHX_MESH_NORMALS_PER_VERTEX)) { na = 3 * f; nb = 3 * f + 1; nc = 3 * f + 2; }  // mesh.cpp:188-192
+          float nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          if (smooth) {
+            if (!m.normals || na >= m.num_normals || nb >= m.num_normals || nc >= m.num_normals) return fail(PHX_ERR_ARG, "normal index out of range");
+            std::memcpy(nn, m.normals + 3 * (size_t)na, 12); std::memcpy(nn + 3, m.normals + 3 * (size_t)nb, 12); std::memcpy(nn + 6, m.normals + 3 * (size_t)nc, 12);
+          }
+          prim_normals.insert(prim_normals.end(), nn, nn + 9);
+        }
+        if (emitter) {  // mesh_t::preprocess -> light_t::make_area (mesh.cpp:108-116), area_light_t (light.cpp:10-45)
+          DevLightTri T{a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], prim, mi | (fs.material << 16), 3 * f};
+          light_tris.push_back(T);
+          const v3 ab(b[0] - a[0], b[1] - a[1], b[2] - a[2]), ac(c[0] - a[0], c[1] - a[1], c[2] - a[2]);
+          L.area += 0.5f * length(cross(ab, ac));  // triangle_t::area, mesh.cpp:293-300; summed in face order (light.cpp:36-39)
+          L.num_tris++;
+        }
+      }
+      if (emitter && L.num_tris) lights.push_back(L);
+    }
+  }
+  if (prim_material.empty()) return fail(PHX_ERR_ARG, "scene has no triangles");
+  if (lights.empty()) return fail(PHX_ERR_ARG, "scene has no emissive face set (reference underflows nlights-1, SURVEY A-19)");
+
+  // sheen_L5: the first sheen lobe of the material table (bsdf.h)
+  float L5 = 0.0f; bool have = false;
+  for (uint32_t i = 0; i < s->num_materials && !have; ++i)
+    for (uint32_t k = 0; k < s->materials[i].num_lobes && k < PHX_MAX_LOBES; ++k)
+      if (s->materials[i].lobes[k].type == PHX_LOBE_SHEEN) { L5 = sheen_L(0.5f, s->materials[i].lobes[k].r); have = true; break; }
+  std::vector<DevMaterial> mats(s->num_materials);
+  for (uint32_t i = 0; i < s->num_materials; ++i)
+    if (bake_material(s->materials[i], L5, mats[i])) return fail(PHX_ERR_ARG, "material with an unknown closure id");
+
+  Bvh8 bvh;
+  const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads);
+
+  int rc;
+  if ((rc = d->d_nodes.upload(bvh.nodes))) return rc;
+  if ((rc = d->d_tris.upload(bvh.tris))) return rc;
+  if ((rc = d->d_prim_material.upload(prim_material))) return rc;
+  if ((rc = d->d_prim_normals.upload(prim_normals))) return rc;
+  if ((rc = d->d_materials.upload(mats))) return rc;
+  if ((rc = d->d_lights.upload(lights))) return rc;
+  if ((rc = d->d_light_tris.upload(light_tris))) return rc;
+
+  DevScene& sc = d->scene;
+  sc.nodes = reinterpret_cast<const uint32_t*>(d->d_nodes.p);
+  sc.tris = d->d_tris.p;
+  sc.prim_material = d->d_prim_material.p;
+  sc.prim_normals = any_smooth ? d->d_prim_normals.p : nullptr;
+  sc.materials = d->d_materials.p;
+  sc.lights = d->d_lights.p; sc.light_tris = d->d_light_tris.p; sc.num_lights = (uint32_t)lights.size();
+  sc.env_material = s->environment_material;
+  std::memcpy(sc.cam_m, s->camera.to_world, sizeof(sc.cam_m));
+  sc.zoom = 1.12f * std::tan(s->camera.fov * 0.5f);  // camera.hpp:113
+  sc.stepx = 1.0f / (float)s->camera.film_width; sc.stepy = 1.0f / (float)s->camera.film_height;
+  sc.ratio = (float)s->camera.film_width / (float)s->camera.film_height;
+  sc.width = s->camera.film_width; sc.height = s->camera.film_height;
+  sc.max_depth = d->opt.path_depth;
+  sc.stack_levels = bvh.depth;
+  d->num_materials = s->num_materials;
+  d->bvh_nodes = bvh.nodes.size();
+  d->bvh_bytes = bvh.nodes.size() * sizeof(Node8) + bvh.tris.size() * sizeof(TriRec);
+  d->num_triangles = prim_material.size();
+  d->preprocessed = true;
+  return PHX_OK;
+}
+
+int phx_dev_start(phx_device* d, const phx_frame* f) {
+  if (!d || !f) return fail(PHX_ERR_ARG, "start: null argument");
+  if (!d->preprocessed) return fail(PHX_ERR_STATE, "start before preprocess");
+  if (d->running) return fail(PHX_ERR_STATE, "start while a frame is running");
+  if (!f->next_tile) return fail(PHX_ERR_ARG, "frame without a tile queue");
+  if (!f->add_tile && !f->device_film) return fail(PHX_ERR_ARG, "frame without a film sink");
+  if (f->primary_components != 3 && f->primary_components != 4) return fail(PHX_ERR_ARG, "primary channel must have 3 or 4 components");
+  d->frame = *f;
+  d->running = true;
+  d->frame_status = PHX_OK;
+  d->driver = std::thread([d]() { d->frame_status = d->run_frame(); });
+  return PHX_OK;
+}
+
+int phx_dev_join(phx_device* d) {
+  if (!d) return fail(PHX_ERR_ARG, "join: null device");
+  if (!d->running) return fail(PHX_ERR_STATE, "join without start");
+  d->driver.join();
+  d->running = false;
+  if (d->frame_status != PHX_OK) g_error = g_error_shared;
+  return d->frame_status;
+}
+
+int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
+  if (!d || !out) return fail(PHX_ERR_ARG, "get_stats: null argument");
+  *out = d->stats;
+  out->bvh_nodes = d->bvh_nodes; out->bvh_bytes = d->bvh_bytes; out->triangles = d->num_triangles;
+  return PHX_OK;
+}
+
+uint32_t phx_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(phx_options); case 1: return sizeof(phx_lobe); case 2: return sizeof(phx_material);
+    case 3: return sizeof(phx_face_set); case 4: return sizeof(phx_mesh); case 5: return sizeof(phx_camera);
+    case 6: return sizeof(phx_scene); case 7: return sizeof(phx_tile); case 8: return sizeof(phx_frame);
+    case 9: return sizeof(phx_stats);
+    default: return 0;
+  }
+}
+
+// ---- tile queue: job::tiles_t (src/jobs/tiles.hpp:10-90) ------------------------------------------------
+phx_tiles* phx_tiles_make(uint32_t width, uint32_t height, uint32_t ts, uint32_t rank, uint32_t world) {
+  if (ts == 0 || world == 0 || rank >= world) { fail(PHX_ERR_ARG, "phx_tiles_make: bad arguments"); return nullptr; }
+  uint32_t ht = width / ts, vt = height / ts;
+  const uint32_t rh = height - ts * vt, rw = width - ts * ht;
+  if (rh > 0) vt++;
+  if (rw > 0) ht++;
+  phx_tiles* q = new phx_tiles();
+  uint32_t id = 0;
+  for (uint32_t y = 0; y < vt; ++y)
+    for (uint32_t x = 0; x < ht; ++x, ++id) {
+      uint32_t tw = ts, th = ts;
+      if (y == vt - 1 && rh > 0) th = rh;
+      if (x == ht - 1 && rw > 0) tw = rw;
+      if (id % world == rank) q->tiles.push_back(phx_tile{x * ts, y * ts, tw, th});
+    }
+  return q;
+}
+int phx_tiles_next(void* tiles, phx_tile* out) {
+  phx_tiles* q = (phx_tiles*)tiles;
+  const uint32_t t = q->cursor++;
+  if (t < q->tiles.size()) { *out = q->tiles[t]; return 1; }
+  return 0;
+}
+uint32_t phx_tiles_count(const phx_tiles* q) { return q ? (uint32_t)q->tiles.size() : 0; }
+void phx_tiles_reset(phx_tiles* q) { if (q) q->cursor = 0; }
+void phx_tiles_free(phx_tiles* q) { delete q; }
+
+// ---- stage-level entry points ----------------------------------------------------------------------------
+int phx_dev_trace(phx_device* d, uint32_t n, const float* o, const float* dir, const float* tmax, int shadow,
+                  float* t, float* u, float* v, uint32_t* prim, uint8_t* hit) {
+  if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "trace before preprocess");
+  if (n == 0) return PHX_OK;
+  HIPCHK(hipSetDevice(d->hip_device));
+  std::vector<float4> ro(n), rd(n), hh(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], 0.0f);
+    rd[i] = make_float4(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], tmax[i]);
+  }
+  DevBuf<float4> a, b, c; int rc;
+  if ((rc = a.upload(ro)) || (rc = b.upload(rd)) || (rc = c.alloc(n))) return rc;
+  launch_trace_rays(d->stream, d->scene, n, a.p, b.p, c.p, shadow);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(d->stream));
+  HIPCHK(hipMemcpy(hh.data(), c.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+  std::vector<TriRec> one(1);
+  std::vector<uint32_t> tri_prim;  // triangle record -> primitive id
+  {
+    std::vector<TriRec> all(d->d_tris.n);
+    HIPCHK(hipMemcpy(all.data(), d->d_tris.p, all.size() * sizeof(TriRec), hipMemcpyDeviceToHost));
+    tri_prim.resize(all.size());
+    for (size_t i = 0; i < all.size(); ++i) tri_prim[i] = all[i].prim;
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t tri; std::memcpy(&tri, &hh[i].w, 4);
+    if (t) t[i] = hh[i].x;
+    if (u) u[i] = hh[i].y;
+    if (v) v[i] = hh[i].z;
+    if (prim) prim[i] = tri == 0xffffffffu ? 0xffffffffu : tri_prim[tri];
+    if (hit) hit[i] = tri != 0xffffffffu;
+  }
+  return PHX_OK;
+}
+
+static int kat_upload(const float* src, size_t n, DevBuf<float>& dst) {
+  int rc = dst.alloc(n); if (rc) return rc;
+  HIPCHK(hipMemcpy(dst.p, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return PHX_OK;
+}
+
+int phx_dev_bsdf_f(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
+  if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "bsdf_f before preprocess");
+  if (material >= d->num_materials) return fail(PHX_ERR_ARG, "material out of range");
+  if (n == 0) return PHX_OK;
+  HIPCHK(hipSetDevice(d->hip_device));
+  DevBuf<float> a, b, c, o; int rc;
+  if ((rc = kat_upload(n3, 3 * (size_t)n, a)) || (rc = kat_upload(wi3, 3 * (size_t)n, b)) || (rc = kat_upload(wo3, 3 * (size_t)n, c)) || (rc = o.alloc(3 * (size_t)n))) return rc;
+  launch_bsdf_f(d->stream, d->d_materials.p + material, n, a.p, b.p, c.p, o.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(d->stream));
+  HIPCHK(hipMemcpy(f3, o.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return PHX_OK;
+}
+
+int phx_dev_bsdf_sample(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* u2,
+                        float* wo3, float* f3, float* pdf, uint32_t* flags) {
+  if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "bsdf_sample before preprocess");
+  if (material >= d->num_materials) return fail(PHX_ERR_ARG, "material out of range");
+  if (n == 0) return PHX_OK;
+  HIPCHK(hipSetDevice(d->hip_device));
+  DevBuf<float> a, b, c, wo, f, p; DevBuf<uint32_t> fl; int rc;
+  if ((rc = kat_upload(n3, 3 * (size_t)n, a)) || (rc = kat_upload(wi3, 3 * (size_t)n, b)) || (rc = kat_upload(u2, 2 * (size_t)n, c)) ||
+      (rc = wo.alloc(3 * (size_t)n)) || (rc = f.alloc(3 * (size_t)n)) || (rc = p.alloc(n)) || (rc = fl.alloc(n))) return rc;
+  launch_bsdf_sample(d->stream, d->d_materials.p + material, n, a.p, b.p, c.p, wo.p, f.p, p.p, fl.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(d->stream));
+  HIPCHK(hipMemcpy(wo3, wo.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(f3, f.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pdf, p.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(flags, fl.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return PHX_OK;
+}
+
+}  // extern "C"
+
+// ---- the frame driver ------------------------------------------------------------------------------------
+int phx_device::run_frame() {
+  HIPCHK(hipSetDevice(hip_device));
+  const auto t0 = std::chrono::steady_clock::now();
+  std::memset(&stats, 0, sizeof(stats));
+  events_used = 0; timed.clear();
+  int rc;
+  if ((rc = dstats.alloc(1)) || (rc = counters.alloc(CNT_WORDS))) return rc;
+  HIPCHK(hipMemsetAsync(dstats.p, 0, sizeof(DevStats), stream));
+  HIPCHK(hipMemsetAsync(counters.p, 0, CNT_WORDS * sizeof(uint32_t), stream));
+
+  // per-spp film jitter shared by all pixels: sampler_t::preprocess (sampling.cpp:98-112) with
+  // sample::stratified_2d (math/sampling.hpp:65-77), numbers from the counter sampler
+  const uint32_t spp = opt.samples_per_pixel;
+  std::vector<float2> jit(spp, make_float2(0.0f, 0.0f));
+  {
+    const uint32_t spd = (uint32_t)std::lroundf(std::sqrt((float)spp));
+    const float step = 1.0f / (float)spd;
+    float dy = 0.0f;
+    for (uint32_t i = 0; i < spd; ++i, dy += step) {
+      float dx = 0.0f;
+      for (uint32_t j = 0; j < spd; ++j, dx += step) {
+        const uint32_t cell = j * spd + i;
+        const uint32_t key = path_key(frame.sampler_seed, FILM_JITTER_STREAM, cell);
+        const float a = dx + draw_f32(key, 0) * step;
+        const float b = dy + draw_f32(key, 1) * step;
+        if (cell < spp) jit[cell] = make_float2(a, b);
+      }
+    }
+  }
+  if ((rc = jitter.upload(jit))) return rc;
+
+  // drain the shared tile queue in batches (cpu.cpp:233-234 pulls one tile at a time)
+  const uint64_t pixel_cap = 8u << 20;  // pixels per batch
+  for (;;) {
+    std::vector<phx_tile> tiles;
+    uint64_t px = 0;
+    phx_tile t;
+    while ((opt.tiles_per_batch == 0 || tiles.size() < opt.tiles_per_batch) && px < pixel_cap && frame.next_tile(frame.tiles_user, &t)) {
+      if (t.w == 0 || t.h == 0 || t.x + t.w > scene.width || t.y + t.h > scene.height) return fail(PHX_ERR_ARG, "tile outside the film");
+      tiles.push_back(t); px += (uint64_t)t.w * t.h;
+    }
+    if (tiles.empty()) break;
+    if ((rc = render_batch(tiles, jit))) return rc;
+    stats.tiles += tiles.size();
+  }
+  HIPCHK(hipStreamSynchronize(stream));
+  DevStats ds;
+  HIPCHK(hipMemcpy(&ds, dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
+  stats.camera_samples = ds.camera_samples; stats.rays_closest = ds.rays_closest; stats.rays_shadow = ds.rays_shadow; stats.rays_masked = ds.rays_masked;
+  for (auto& te : timed) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));
+    if (te.second == 0) { stats.closest_ms += ms; stats.trace_launches++; }
+    else if (te.second == 1) { stats.shadow_ms += ms; stats.trace_launches++; }
+    else stats.shade_ms += ms;
+  }
+  stats.trace_ms = stats.closest_ms + stats.shadow_ms;
+  stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return PHX_OK;
+}
+
+int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit) {
+  (void)jit;
+  int rc;
+  uint32_t P = 0;
+  for (auto& t : tiles) P += t.w * t.h;
+  const uint32_t spp = opt.samples_per_pixel;
+  uint32_t S = opt.samples_in_flight;
+  if (S == 0) { const uint64_t budget = 16u << 20; S = (uint32_t)std::max<uint64_t>(1, budget / P); }
+  S = std::min(S, spp);
+  const size_t npaths = (size_t)P * S;
+  if (npaths >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");
+  const uint32_t xs = frame.primary_components + (frame.normals_channel ? 3u : 0u);
+
+  std::vector<uint32_t> xy(P);
+  {
+    uint32_t k = 0;
+    for (auto& t : tiles)
+      for (uint32_t y = 0; y < t.h; ++y)
+        for (uint32_t x = 0; x < t.w; ++x) xy[k++] = (t.x + x) | ((t.y + y) << 16);
+  }
+  if ((rc = pix_xy.upload(xy))) return rc;
+  for (int q = 0; q < 2; ++q) if ((rc = ro[q].alloc(npaths)) || (rc = rd[q].alloc(npaths))) return rc;
+  if ((rc = hit.alloc(npaths)) || (rc = so.alloc(npaths)) || (rc = sd.alloc(npaths)) || (rc = sc.alloc(npaths)) ||
+      (rc = pb.alloc(npaths)) || (rc = pr.alloc(npaths)) || (rc = acc.alloc((size_t)P * xs))) return rc;
+  if (frame.normals_channel && (rc = pn.alloc(npaths))) return rc;
+  HIPCHK(hipMemsetAsync(acc.p, 0, (size_t)P * xs * sizeof(float), stream));
+
+  PassBuffers B{};
+  for (int q = 0; q < 2; ++q) { B.ro[q] = ro[q].p; B.rd[q] = rd[q].p; }
+  B.hit = hit.p; B.so = so.p; B.sd = sd.p; B.sc = sc.p; B.pb = pb.p; B.pr = pr.p;
+  B.pn = frame.normals_channel ? pn.p : nullptr;
+  B.counters = counters.p; B.stats = dstats.p; B.pix_xy = pix_xy.p; B.jitter = jitter.p; B.acc = acc.p;
+  B.num_pixels = P; B.xstride = xs; B.normals_offset = frame.normals_channel ? frame.primary_components : 0;
+  B.seed = frame.sampler_seed;
+
+  const float inv = 1.0f / (float)(spp * opt.paths_per_sample);  // cpu.cpp:191
+  auto timed_launch = [&](int kind, auto&& fn) -> int {
+    hipEvent_t e0, e1; int r;
+    if ((r = next_event(&e0)) || (r = next_event(&e1))) return r;
+    HIPCHK(hipEventRecord(e0, stream));
+    fn();
+    HIPCHK(hipEventRecord(e1, stream));
+    timed.emplace_back(events_used - 2, kind);
+    return PHX_OK;
+  };
+  for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+    const uint32_t ns = std::min(S, spp - s0);
+    const uint32_t cap = P * ns;
+    if ((rc = timed_launch(2, [&]() { launch_generate(stream, scene, B, s0, ns); }))) return rc;
+    int q = 0;
+    for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
+      if ((rc = timed_launch(0, [&]() { launch_trace_closest(stream, scene, B, q, cap); }))) return rc;
+      if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, cap, s0); }))) return rc;
+      if ((rc = timed_launch(1, [&]() { launch_trace_shadow(stream, scene, B, cap); }))) return rc;
+      q ^= 1;
+    }
+    if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
+    HIPCHK(hipGetLastError());
+  }
+  // film_t<>::add_tile (film.hpp:12-15)
+  if (frame.device_film) {
+    launch_scatter_film(stream, B, frame.device_film, scene.width);
+    HIPCHK(hipGetLastError());
+  }
+  if (frame.add_tile) {
+    const size_t nfl = (size_t)P * xs;
+    if (nfl > h_acc_n) {
+      if (h_acc) (void)hipHostFree(h_acc);
+      HIPCHK(hipHostMalloc((void**)&h_acc, nfl * sizeof(float), hipHostMallocDefault));
+      h_acc_n = nfl;
+    }
+    HIPCHK(hipMemcpyAsync(h_acc, acc.p, nfl * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    size_t off = 0;
+    for (auto& t : tiles) {
+      frame.add_tile(frame.film_user, (int32_t)t.x, (int32_t)t.y, (int32_t)t.w, (int32_t)t.h, h_acc + off, xs, xs * t.w);
+      off += (size_t)t.w * t.h * xs;
+    }
+  } else {
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+  return PHX_OK;
+}

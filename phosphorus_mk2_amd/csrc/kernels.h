@@ -1,0 +1,76 @@
+// kernels.h — device-side data layout of the wavefront path tracer and the launch entry points
+// implemented in kernels.hip.  One "pass" carries P pixels x S samples = npaths paths through
+// generate -> [trace closest -> shade/NEE/integrate -> trace shadow] x depth -> film.
+//
+// HBM layout (all records 16 B so that a wave reads/writes 1 KiB per instruction):
+//   ray queue (x2, ping-pong)  ro[i] = (o.xyz, path | SPECULAR<<31)   rd[i] = (d.xyz, tmax)
+//   hit records                hit[i] = (t, u, v, triangle-record index)
+//   shadow queue               so[i] = (o.xyz, path)  sd[i] = (d.xyz, tmax)  sc[i] = (beta*Li rgb, 0)
+//   path state (by path id)    pb[path] = (beta.rgb, depth)   pr[path] = (radiance.rgb, 0)
+//   path id = sample_in_pass * P + pixel_in_batch  (neighbouring lanes = neighbouring pixels)
+// These take the place of ray_t<1024> / interaction_t<1024> / active_t<1024> / spt::state_t<1024>
+// (reference src/state.hpp:40-282, src/kernels/cpu/spt.hpp:23-64): the interaction record is never
+// materialised — shade, NEE and integrate are one kernel.
+#pragma once
+#include "bsdf.h"
+#include "bvh8.h"
+
+#include <hip/hip_runtime.h>
+
+namespace phx {
+
+struct DevLight { uint32_t first_tri, num_tris; float area; uint32_t material; };
+struct DevLightTri { float ax, ay, az, bx, by, bz, cx, cy, cz; uint32_t prim; uint32_t mesh_mat; uint32_t face; };
+
+struct DevScene {
+  const uint32_t* nodes;          // Node8 as 20 words each
+  const TriRec* tris;
+  const uint32_t* prim_material;  // per primitive (scene_t::triangles() order): material | smooth << 31
+  const float* prim_normals;      // 9 floats per primitive (n0,n1,n2) or nullptr when no face is smooth
+  const DevMaterial* materials;
+  const DevLight* lights;
+  const DevLightTri* light_tris;
+  uint32_t num_lights;
+  int32_t env_material;
+  float cam_m[16];
+  float zoom, stepx, stepy, ratio;
+  uint32_t width, height;
+  uint32_t max_depth;
+  uint32_t stack_levels;          // BVH depth
+};
+
+enum { CNT_IN = 0, CNT_OUT = 1, CNT_SHADOW = 2, CNT_WORDS = 8 };
+struct DevStats { unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples; };
+
+struct PassBuffers {
+  float4* ro[2]; float4* rd[2];
+  float4* hit;
+  float4* so; float4* sd; float4* sc;
+  float4* pb; float4* pr;
+  float4* pn;                 // primary normal + hit flag per path (only when the normals channel is on)
+  uint32_t* counters;         // CNT_WORDS
+  DevStats* stats;
+  const uint32_t* pix_xy;     // per pixel of the batch: x | y << 16 (film coordinates)
+  const float2* jitter;       // per spp index: film jitter shared by all pixels (src/sampling.cpp:98-112)
+  float* acc;                 // batch render buffer: tile after tile, interleaved xstride floats per pixel
+  uint32_t num_pixels;        // P
+  uint32_t xstride;
+  uint32_t normals_offset;    // offset of channel "normals" inside a pixel, 0 = off
+  uint64_t seed;
+};
+
+// launches (all asynchronous on `stream`)
+void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples);
+void launch_trace_closest(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity);
+void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity, uint32_t sample0);
+void launch_trace_shadow(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t capacity);
+void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);
+void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width);
+
+// stage-level entry points (synchronous helpers for the parity tests)
+void launch_trace_rays(hipStream_t stream, const DevScene& sc, uint32_t n, const float4* ro, const float4* rd, float4* hit, int any);
+void launch_bsdf_f(hipStream_t stream, const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3);
+void launch_bsdf_sample(hipStream_t stream, const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* u2,
+                        float* wo3, float* f3, float* pdf, uint32_t* flags);
+
+}  // namespace phx

@@ -1,0 +1,371 @@
+// kernels.hip — hand-written gfx950 kernels of the wavefront path tracer (see kernels.h for the
+// HBM layout).  One ray / path per lane, 64-lane wavefronts, 256-thread workgroups.
+//
+//   k_generate  camera::perspective_kernel_t (reference src/kernels/cpu/camera.hpp:80-159) + spt::state_t::reset
+//   k_trace     stream_mbvh_kernel_t::trace (src/kernels/cpu/stream_bvh_kernel.cpp:18-161) re-thought per lane:
+//               BVH8 nodelets, (base,mask) group stack in LDS, closest-hit and any-hit variants
+//   k_shade     deferred_shading_kernel_t (deferred_shading_kernel.hpp:20-72) + light_sampler_t (spt.hpp:95-149)
+//               + integrator_t (spt.hpp:161-328) fused; survivors and shadow rays are appended to their
+//               queues with __ballot/__popcll wave compaction (one atomic per wave)
+//   k_film      the per-sample film add of tile_renderer_t::render_tile (src/xpu/cpu.cpp:175-198)
+#include "kernels.h"
+
+namespace phx {
+
+#define PHX_BLOCK 256
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// XCD-aware block -> work-chunk map: blocks b and b+8 share an XCD (L2), so give each XCD a
+// contiguous eighth of the live queue instead of every eighth block.
+__device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t count) {
+  const uint32_t nblk = (count + PHX_BLOCK - 1) / PHX_BLOCK;
+  const uint32_t per = (nblk + 7u) >> 3;
+  const uint32_t chunk = blockIdx.x >> 3;
+  if (chunk >= per) return 0xffffffffu / PHX_BLOCK;  // beyond this XCD's share: the caller's bound check exits
+  return (blockIdx.x & 7u) * per + chunk;
+}
+
+// append-slot allocation for the lanes of a wave that `want` one: one atomic per wave
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
+  const unsigned long long mask = __ballot(want);
+  if (!want) return 0;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, (int)leader);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ---- generate -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PHX_BLOCK) k_generate(DevScene sc, PassBuffers pb, uint32_t sample0, uint32_t num_samples) {
+  const uint32_t path = blockIdx.x * PHX_BLOCK + threadIdx.x;
+  const uint32_t npaths = pb.num_pixels * num_samples;
+  if (path == 0) {
+    pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0;
+    atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
+  }
+  if (path >= npaths) return;
+  const uint32_t s = path / pb.num_pixels, pix = path - s * pb.num_pixels;
+  const uint32_t xy = pb.pix_xy[pix];
+  const float sx = (float)(xy & 0xffffu), sy = (float)(xy >> 16);
+  const float2 jit = pb.jitter[sample0 + s];
+  const float ndcy = 0.5f - (-0.5f + sy) * sc.stepy;
+  const float ndcx = (-0.5f + sx) * sc.stepx - 0.5f;
+  v3 d(jit.x, jit.y, -1.0f);
+  d.x = (ndcx + d.x * sc.stepx) * sc.ratio * sc.zoom;
+  d.y = (ndcy + d.y * sc.stepy) * sc.zoom;
+  const float ool = 1.0f / sqrtf(sdot(d, d));
+  d = v3(d.x * ool, d.y * ool, d.z * ool);
+  const float* M = sc.cam_m;
+  v3 p, w;
+  { float t = 0.0f * M[0]; t = fmaf(0.0f, M[4], t); t = fmaf(0.0f, M[8], t); p.x = t + M[12]; }
+  { float t = 0.0f * M[1]; t = fmaf(0.0f, M[5], t); t = fmaf(0.0f, M[9], t); p.y = t + M[13]; }
+  { float t = 0.0f * M[2]; t = fmaf(0.0f, M[6], t); t = fmaf(0.0f, M[10], t); p.z = t + M[14]; }
+  { float t = d.x * M[0]; t = fmaf(d.y, M[4], t); w.x = fmaf(d.z, M[8], t); }
+  { float t = d.x * M[1]; t = fmaf(d.y, M[5], t); w.y = fmaf(d.z, M[9], t); }
+  { float t = d.x * M[2]; t = fmaf(d.y, M[6], t); w.z = fmaf(d.z, M[10], t); }
+  pb.ro[0][path] = make_float4(p.x, p.y, p.z, u2f(path));
+  pb.rd[0][path] = make_float4(w.x, w.y, w.z, FLT_MAX);
+  pb.pb[path] = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));
+  pb.pr[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (pb.pn) pb.pn[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---- trace ----------------------------------------------------------------------------------------
+template <int LEVELS>
+struct LdsStack {
+  uint2* base;  // &lds[threadIdx.x]; entry k lives at base[k * PHX_BLOCK]: conflict-free 8-byte accesses
+  int sp;
+  __device__ __forceinline__ void push(uint32_t b, uint32_t h) { base[sp * PHX_BLOCK] = make_uint2(b, h); ++sp; }
+  __device__ __forceinline__ void pop(uint32_t& b, uint32_t& h) { --sp; const uint2 e = base[sp * PHX_BLOCK]; b = e.x; h = e.y; }
+  __device__ __forceinline__ bool empty() const { return sp == 0; }
+};
+
+template <int LEVELS>
+__global__ void __launch_bounds__(PHX_BLOCK) k_trace_closest(DevScene sc, PassBuffers pb, int q) {
+  __shared__ uint2 lds[LEVELS * PHX_BLOCK];
+  const uint32_t count = pb.counters[q];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    pb.counters[q ^ 1] = 0; pb.counters[CNT_SHADOW] = 0;
+    atomicAdd(&pb.stats->rays_closest, (unsigned long long)count);
+  }
+  const uint32_t i = xcd_chunked_block(count) * PHX_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const float4 a = pb.ro[q][i], b = pb.rd[q][i];
+  LdsStack<LEVELS> st{lds + threadIdx.x, 0};
+  Hit h;
+  traverse8<false>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
+  pb.hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri));
+}
+
+template <int LEVELS>
+__global__ void __launch_bounds__(PHX_BLOCK) k_trace_shadow(DevScene sc, PassBuffers pb) {
+  __shared__ uint2 lds[LEVELS * PHX_BLOCK];
+  const uint32_t count = pb.counters[CNT_SHADOW];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats->rays_shadow, (unsigned long long)count);
+  const uint32_t i = xcd_chunked_block(count) * PHX_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const float4 a = pb.so[i], b = pb.sd[i];
+  LdsStack<LEVELS> st{lds + threadIdx.x, 0};
+  Hit h;
+  const bool occluded = traverse8<true>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
+  if (!occluded) {  // out += beta * li   (spt.hpp:184-186); one shadow ray per path and step: no atomics
+    const uint32_t path = f2u(a.w);
+    const float4 c = pb.sc[i];
+    float4 r = pb.pr[path];
+    r.x += c.x; r.y += c.y; r.z += c.z;
+    pb.pr[path] = r;
+  }
+}
+
+template <int LEVELS, bool ANY>
+__global__ void __launch_bounds__(PHX_BLOCK) k_trace_rays(DevScene sc, uint32_t n, const float4* ro, const float4* rd, float4* hit) {
+  __shared__ uint2 lds[LEVELS * PHX_BLOCK];
+  const uint32_t i = blockIdx.x * PHX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = ro[i], b = rd[i];
+  LdsStack<LEVELS> st{lds + threadIdx.x, 0};
+  Hit h;
+  traverse8<ANY>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
+  hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri));
+}
+
+// ---- shade + next-event estimation + integrate ------------------------------------------------------
+__device__ __forceinline__ v3 shading_normal(const DevScene& sc, uint32_t prim, bool smooth, const v3& e0, const v3& e1, float u, float v) {
+  if (smooth) {  // mesh_t::shading_parameters, src/mesh.cpp:187-199
+    const float w = 1 - u - v;
+    const float* pn = sc.prim_normals + 9 * (size_t)prim;
+    const v3 n0(pn[0], pn[1], pn[2]), n1(pn[3], pn[4], pn[5]), n2(pn[6], pn[7], pn[8]);
+    return normalize_inplace(w * n0 + u * n1 + v * n2);
+  }
+  return normalize_inplace(cross(e0, e1));  // (v1-v0) x (v2-v0), never flipped (mesh.cpp:201-215)
+}
+
+__device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/utils/color.hpp:13-16
+  return (float)0.212671 * c.x + (float)0.715160 * c.y + (float)0.072169 * c.z;
+}
+
+__global__ void __launch_bounds__(PHX_BLOCK) k_shade(DevScene sc, PassBuffers pb, int q, uint32_t sample0) {
+  const uint32_t count = pb.counters[q];
+  const uint32_t i = blockIdx.x * PHX_BLOCK + threadIdx.x;
+  const bool live = i < count;
+  bool alive = false, want_shadow = false, masked = false;
+  uint32_t path = 0, next_specular = 0;
+  v3 nxt_o, nxt_d, sh_o, sh_d, contrib;
+  float sh_t = 0.0f;
+  if (live) {
+    const float4 a = pb.ro[q][i], b = pb.rd[q][i], h = pb.hit[i];
+    const uint32_t pbits = f2u(a.w);
+    path = pbits & 0x7fffffffu;
+    const bool specular = (pbits >> 31) != 0;
+    const float4 bd = pb.pb[path];
+    float4 rr = pb.pr[path];
+    v3 beta(bd.x, bd.y, bd.z), rad(rr.x, rr.y, rr.z);
+    uint32_t depth = f2u(bd.w);
+    const uint32_t s = path / pb.num_pixels, pix = path - s * pb.num_pixels;
+    const uint32_t xy = pb.pix_xy[pix];
+    const uint32_t key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+    const uint32_t tri = f2u(h.w);
+    const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
+    if (tri != 0xffffffffu) {
+      const TriRec T = sc.tris[tri];
+      const uint32_t pm = sc.prim_material[T.prim];
+      const DevMaterial& m = sc.materials[pm & 0x7fffffffu];
+      const v3 p = o + d * h.x;            // hits.p = p + wi*d
+      const v3 wo = -d;                    // hits.wi = -wi
+      const v3 n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+      if (pb.pn && depth == 0) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
+      const v3 e(m.ex, m.ey, m.ez);
+      if (depth == 0 || specular) rad = rad + beta * e;  // spt.hpp:177-179
+      // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
+      {
+        const uint32_t b0 = depth * DIMS_PER_STEP;
+        const float pick = draw_f32(key, b0 + DIM_LIGHT_PICK), lu = draw_f32(key, b0 + DIM_LIGHT_U), lv = draw_f32(key, b0 + DIM_LIGHT_V);
+        const float nlf = (float)sc.num_lights;
+        uint32_t l = (uint32_t)floorf(pick * nlf);
+        if (l > sc.num_lights - 1) l = sc.num_lights - 1;
+        const DevLight L = sc.lights[l];
+        const float numf = (float)L.num_tris;
+        uint32_t ti = (uint32_t)floorf(lu * numf);  // uniform by index (light.cpp:55), pdf = 1/area
+        if (ti > L.num_tris - 1) ti = L.num_tris - 1;
+        const float remapped = fminf(lu * numf - (float)ti, 1.0f - FLT_EPSILON);
+        const DevLightTri LT = sc.light_tris[L.first_tri + ti];
+        const float x = sqrtf(remapped);
+        const float bu = 1 - x, bv = lv * x;     // triangle_t::sample, mesh.cpp:318-324
+        const v3 la(LT.ax, LT.ay, LT.az), lb(LT.bx, LT.by, LT.bz), lc(LT.cx, LT.cy, LT.cz);
+        const v3 P = bu * la + bv * lb + (1 - bu - bv) * lc;
+        const float lpdf = (1.0f / L.area) / nlf;
+        sh_o = v3(p.x + n.x * 0.0001f, p.y + n.y * 0.0001f, p.z + n.z * 0.0001f);
+        v3 wl = P - sh_o;
+        const float l2 = sdot(wl, wl);
+        const float dist = sqrtf(l2) - 0.0001f;
+        const float oolen = 1.0f / sqrtf(l2);
+        wl = v3(wl.x * oolen, wl.y * oolen, wl.z * oolen);
+        if (sdot(n, wl) >= 0.0f) {
+          // li(), spt.hpp:212-255 — evaluated before the occlusion test; added by k_trace_shadow if unoccluded
+          const v3 f = bsdf_f(m, n, wl, wo);
+          const uint32_t lpm = sc.prim_material[LT.prim];
+          const v3 ln = shading_normal(sc, LT.prim, (lpm >> 31) != 0, lb - la, lc - la, bu, bv);
+          const DevMaterial& lm = sc.materials[L.material];
+          const v3 le(lm.ex, lm.ey, lm.ez);
+          const float pdf = lpdf * dist * dist / fabsf(dot(ln, -wl));
+          const v3 li = ((le * 4.0f) * f) * (1.0f / pdf);
+          contrib = beta * li;
+          sh_d = wl; sh_t = dist;
+          want_shadow = true;
+        } else {
+          masked = true;
+        }
+      }
+      // ---- integrate: ++depth, russian roulette, bsdf sampling (spt.hpp:188-190, 257-328)
+      depth += 1;
+      float wgt = 1.0f;
+      alive = depth < sc.max_depth;
+      if (alive && depth >= 3) {
+        const float qq = fmaxf(0.05f, 1.0f - luminance(beta));
+        const float xi = draw_f32(key, (depth - 1u) * DIMS_PER_STEP + DIM_RR);
+        alive = xi >= qq;
+        if (alive) wgt = (1.0f / (1.0f - qq));
+      }
+      beta = beta * wgt;
+      if (alive) {
+        const uint32_t b1 = (depth - 1u) * DIMS_PER_STEP;
+        v3 sampled; float pdf; uint32_t fl;
+        const v3 f = bsdf_sample(m, n, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, sampled, pdf, fl);
+        if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) {
+          alive = false;
+        } else {
+          const float weight = dot(n, sampled);
+          beta = beta * (f * (fabsf(weight) / pdf));
+          const float off = (weight < 0.0f) ? -0.0001f : 0.0001f;
+          nxt_o = p + n * off;
+          nxt_d = sampled;
+          next_specular = (fl & B_SPECULAR) ? 1u : 0u;
+        }
+      }
+    } else {
+      // miss: environment lighting (deferred_shading_kernel.hpp:65-70, spt.hpp:199-202)
+      v3 e(0.0f);
+      if (sc.env_material >= 0) { const DevMaterial& m = sc.materials[sc.env_material]; e = v3(m.ex, m.ey, m.ez); }
+      rad = rad + beta * e;
+      masked = true;  // a miss still occupies a (MASKED|SHADOW) slot in the reference's shadow stream (spt.hpp:138-141)
+    }
+    pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));
+    pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+  }
+  // ---- stream compaction: survivors -> next ray queue, unmasked NEE rays -> shadow queue
+  const uint32_t no = wave_append(alive, &pb.counters[q ^ 1]);
+  if (alive) {
+    pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
+    pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
+  }
+  const uint32_t ns = wave_append(want_shadow, &pb.counters[CNT_SHADOW]);
+  if (want_shadow) {
+    pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
+    pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
+    pb.sc[ns] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+  }
+  const unsigned long long mm = __ballot(masked);
+  if (mm && __lane_id() == (uint32_t)__ffsll((long long)mm) - 1u) atomicAdd(&pb.stats->rays_masked, (unsigned long long)__popcll(mm));
+}
+
+// ---- film -------------------------------------------------------------------------------------------
+// channels.primary->add(x, y, r * (1.0f / (spp * pps))) per sample, in sample order (cpu.cpp:175-198)
+__global__ void __launch_bounds__(PHX_BLOCK) k_film(PassBuffers pb, uint32_t num_samples, float inv) {
+  const uint32_t pix = blockIdx.x * PHX_BLOCK + threadIdx.x;
+  if (pix >= pb.num_pixels) return;
+  float* out = pb.acc + (size_t)pix * pb.xstride;
+  float r = out[0], g = out[1], b = out[2];
+  for (uint32_t s = 0; s < num_samples; ++s) {
+    const float4 c = pb.pr[(size_t)s * pb.num_pixels + pix];
+    r += c.x * inv; g += c.y * inv; b += c.z * inv;
+    if (pb.pn) {
+      const float4 n = pb.pn[(size_t)s * pb.num_pixels + pix];
+      if (n.w != 0.0f) { out[pb.normals_offset] = n.x; out[pb.normals_offset + 1] = n.y; out[pb.normals_offset + 2] = n.z; }
+    }
+  }
+  out[0] = r; out[1] = g; out[2] = b;
+}
+
+// batch render buffer -> full-frame device film (film_t::add_tile for a device-resident sink)
+__global__ void __launch_bounds__(PHX_BLOCK) k_scatter_film(PassBuffers pb, float* film, uint32_t film_width) {
+  const uint32_t pix = blockIdx.x * PHX_BLOCK + threadIdx.x;
+  if (pix >= pb.num_pixels) return;
+  const uint32_t xy = pb.pix_xy[pix];
+  const float* src = pb.acc + (size_t)pix * pb.xstride;
+  float* dst = film + ((size_t)(xy >> 16) * film_width + (xy & 0xffffu)) * pb.xstride;
+  for (uint32_t c = 0; c < pb.xstride; ++c) dst[c] = src[c];
+}
+
+// ---- KAT kernels ------------------------------------------------------------------------------------
+__global__ void k_bsdf_f(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const v3 f = bsdf_f(*mat, v3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]),
+                      v3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]));
+  f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
+}
+__global__ void k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* u2,
+                              float* wo3, float* f3, float* pdf, uint32_t* flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  v3 wo; float p; uint32_t fl;
+  v3 f = bsdf_sample(*mat, v3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), u2[2 * i], u2[2 * i + 1],
+                     v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo, p, fl);
+  if (p == 0.0f) { wo = v3(0.0f); f = v3(0.0f); fl = 0; }
+  wo3[3 * i] = wo.x; wo3[3 * i + 1] = wo.y; wo3[3 * i + 2] = wo.z;
+  f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z; pdf[i] = p; flags[i] = fl;
+}
+
+// ---- launches ---------------------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint32_t n) { return (n + PHX_BLOCK - 1) / PHX_BLOCK; }
+// XCD-chunked kernels index past the plain block count when it is not a multiple of 8
+static inline uint32_t blocks_for_chunked(uint32_t n) { uint32_t b = blocks_for(n); return ((b + 7u) / 8u) * 8u; }
+
+void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples) {
+  const uint32_t npaths = pb.num_pixels * num_samples;
+  hipLaunchKernelGGL(k_generate, dim3(blocks_for(npaths)), dim3(PHX_BLOCK), 0, stream, sc, pb, sample0, num_samples);
+}
+void launch_trace_closest(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity) {
+  const dim3 g(blocks_for_chunked(capacity)), b(PHX_BLOCK);
+  if (sc.stack_levels <= 12) hipLaunchKernelGGL(k_trace_closest<12>, g, b, 0, stream, sc, pb, q);
+  else if (sc.stack_levels <= 24) hipLaunchKernelGGL(k_trace_closest<24>, g, b, 0, stream, sc, pb, q);
+  else hipLaunchKernelGGL(k_trace_closest<64>, g, b, 0, stream, sc, pb, q);
+}
+void launch_trace_shadow(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t capacity) {
+  const dim3 g(blocks_for_chunked(capacity)), b(PHX_BLOCK);
+  if (sc.stack_levels <= 12) hipLaunchKernelGGL(k_trace_shadow<12>, g, b, 0, stream, sc, pb);
+  else if (sc.stack_levels <= 24) hipLaunchKernelGGL(k_trace_shadow<24>, g, b, 0, stream, sc, pb);
+  else hipLaunchKernelGGL(k_trace_shadow<64>, g, b, 0, stream, sc, pb);
+}
+void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity, uint32_t sample0) {
+  hipLaunchKernelGGL(k_shade, dim3(blocks_for(capacity)), dim3(PHX_BLOCK), 0, stream, sc, pb, q, sample0);
+}
+void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
+  hipLaunchKernelGGL(k_film, dim3(blocks_for(pb.num_pixels)), dim3(PHX_BLOCK), 0, stream, pb, num_samples, inv);
+}
+void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width) {
+  hipLaunchKernelGGL(k_scatter_film, dim3(blocks_for(pb.num_pixels)), dim3(PHX_BLOCK), 0, stream, pb, device_film, film_width);
+}
+void launch_trace_rays(hipStream_t stream, const DevScene& sc, uint32_t n, const float4* ro, const float4* rd, float4* hit, int any) {
+  const dim3 g(blocks_for(n)), b(PHX_BLOCK);
+  if (sc.stack_levels <= 24) {
+    if (any) hipLaunchKernelGGL((k_trace_rays<24, true>), g, b, 0, stream, sc, n, ro, rd, hit);
+    else hipLaunchKernelGGL((k_trace_rays<24, false>), g, b, 0, stream, sc, n, ro, rd, hit);
+  } else {
+    if (any) hipLaunchKernelGGL((k_trace_rays<64, true>), g, b, 0, stream, sc, n, ro, rd, hit);
+    else hipLaunchKernelGGL((k_trace_rays<64, false>), g, b, 0, stream, sc, n, ro, rd, hit);
+  }
+}
+void launch_bsdf_f(hipStream_t stream, const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
+  hipLaunchKernelGGL(k_bsdf_f, dim3((n + 63) / 64), dim3(64), 0, stream, mat, n, n3, wi3, wo3, f3);
+}
+void launch_bsdf_sample(hipStream_t stream, const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* u2,
+                        float* wo3, float* f3, float* pdf, uint32_t* flags) {
+  hipLaunchKernelGGL(k_bsdf_sample, dim3((n + 63) / 64), dim3(64), 0, stream, mat, n, n3, wi3, u2, wo3, f3, pdf, flags);
+}
+
+}  // namespace phx
