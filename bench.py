@@ -88,11 +88,9 @@ def main():
     if use_dist:
         # torch first: libphx_hip.so then binds to the HIP runtime torch already loaded (one runtime per process)
         import torch
-        import torch.distributed as dist
+        from phosphorus_mk2_amd import dist as pdist
         torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist = pdist.init_process_group("nccl", rank, world, torch.device("cuda", local_rank))
     from phosphorus_mk2_amd import scenes, xpu
     xpu.load_library()  # raises if the HIP extension is missing: no fallback
 
@@ -124,7 +122,7 @@ def main():
             torch.cuda.synchronize()
             dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
             dev.join()  # join() synchronises the device's stream
-            dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)  # the single film collective (RCCL over xGMI)
+            pdist.reduce_film(film_dev, dst=0)  # the single film collective (RCCL over xGMI)
         else:
             film_host.data[:] = 0
             dev.start(scene, xpu.FrameState(args.seed, tiles, film_host))
@@ -145,8 +143,8 @@ def main():
     elapsed = time.perf_counter() - t0
     rays_local = acc["closest"] + acc["shadow"]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
-        r = torch.tensor([rays_local], dtype=torch.float64, device="cuda"); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays_total = float(r.item())
+        elapsed = pdist.max_over_ranks(elapsed, "cuda")
+        rays_total = pdist.sum_over_ranks(rays_local, "cuda")
     else:
         rays_total = float(rays_local)
 

@@ -260,21 +260,29 @@ inline void packet_vs_ray(const packet8_t& pk, rays_t& R, uint32_t index) {
   }
 }
 
+// The reference's AVX2 wrapper semantics on one lane (src/math/simd/float8.hpp):
+//   select(m,l,r) = _mm256_blendv_ps(l,r,m): r where the mask's sign bit is set, else l   (:103-105)
+//   max(a,b) = _mm256_max_ps: a > b ? a : b  (b when either is NaN); min likewise with <   (:59-65)
+//   compares are ordered (false on NaN), all-ones / all-zeros lanes                         (:67-85)
+// Checked against the reference's own object code in tests/golden/ref_subset_vectors.npz.
+inline float simd_select(bool mask, float l, float r) { return mask ? r : l; }
+inline float simd_max(float a, float b) { return a > b ? a : b; }
+inline float simd_min(float a, float b) { return a < b ? a : b; }
+// __bscf (src/utils/compiler.hpp:6-14): index of the lowest set bit, which is then cleared
+inline uint64_t bscf(uint64_t& v) { uint64_t i = 0; while (!((v >> i) & 1ull)) ++i; v &= v - 1; return i; }
+
 // simd::intersect<8> for one child box (aabb.hpp:26-62); ood = 1/dir (or RCPPS in approx mode)
 inline bool slab_literal(const node8_t& n, int c, const V3& o, const V3& ood, float d, float& dist) {
   const float bminx = n.bounds[c], bminy = n.bounds[c + 8], bminz = n.bounds[c + 16];
   const float bmaxx = n.bounds[c + 24], bmaxy = n.bounds[c + 32], bmaxz = n.bounds[c + 40];
-  // select(m,l,r) = blendv(l,r,m): picks r where the mask is set (float8.hpp:103)
-  float nx = (ood.x >= 0.0f) ? bminx : bmaxx, fx = (ood.x >= 0.0f) ? bmaxx : bminx;
-  float ny = (ood.y >= 0.0f) ? bminy : bmaxy, fy = (ood.y >= 0.0f) ? bmaxy : bminy;
-  float nz = (ood.z >= 0.0f) ? bminz : bmaxz, fz = (ood.z >= 0.0f) ? bmaxz : bminz;
+  const bool gx = ood.x >= 0.0f, gy = ood.y >= 0.0f, gz = ood.z >= 0.0f;
+  float nx = simd_select(gx, bmaxx, bminx), fx = simd_select(gx, bminx, bmaxx);  // aabb.hpp:38-43
+  float ny = simd_select(gy, bmaxy, bminy), fy = simd_select(gy, bminy, bmaxy);
+  float nz = simd_select(gz, bmaxz, bminz), fz = simd_select(gz, bminz, bmaxz);
   nx = (nx - o.x) * ood.x; ny = (ny - o.y) * ood.y; nz = (nz - o.z) * ood.z;
   fx = (fx - o.x) * ood.x; fy = (fy - o.y) * ood.y; fz = (fz - o.z) * ood.z;
-  // _mm256_max_ps(a,b) = a > b ? a : b (returns b on NaN)
-  auto mx = [](float a, float b) { return a > b ? a : b; };
-  auto mn = [](float a, float b) { return a < b ? a : b; };
-  const float nn = mx(mx(nx, ny), mx(nz, 0.0f));
-  const float ff = mn(mn(fx, fy), mn(fz, d));
+  const float nn = simd_max(simd_max(nx, ny), simd_max(nz, 0.0f));
+  const float ff = simd_min(simd_min(fx, fy), simd_min(fz, d));
   dist = nn;
   return nn <= ff;
 }

@@ -575,6 +575,21 @@ void orc_sincos(uint32_t n, const float* x, float* s, float* c) { for (uint32_t 
 void orc_exp_log_pow(uint32_t n, const float* x, const float* y, float* e, float* l, float* p) {
   for (uint32_t i = 0; i < n; ++i) { e[i] = m::expf_(x[i]); l[i] = m::logf_(x[i]); p[i] = m::powf_(x[i], y[i]); }
 }
+// restated AVX2-wrapper semantics (obvh.h), exported for the check against oracle/_ref's vectors
+void orc_simd_select(uint32_t n, const uint32_t* mask_bits, const float* l, const float* r, float* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = simd_select((mask_bits[i] >> 31) != 0, l[i], r[i]);
+}
+void orc_simd_minmax(uint32_t n, int is_max, const float* l, const float* r, float* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = is_max ? simd_max(l[i], r[i]) : simd_min(l[i], r[i]);
+}
+void orc_simd_cmp(uint32_t n, int op, const float* l, const float* r, uint32_t* out_bits) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const bool m = op == 0 ? (l[i] < r[i]) : op == 1 ? (l[i] <= r[i]) : op == 2 ? (l[i] > r[i]) : (l[i] >= r[i]);
+    out_bits[i] = m ? 0xffffffffu : 0u;
+  }
+}
+uint64_t orc_bscf(uint64_t v, uint64_t* rest) { uint64_t x = v; uint64_t i = bscf(x); *rest = x; return i; }
+void orc_radians(uint32_t n, const float* a, float* out) { for (uint32_t i = 0; i < n; ++i) out[i] = (float)((double)a[i] * (kPi / (double)180.0f)); }
 void orc_mt19937_head(uint32_t n, float* out) { seq_rng_t r; for (uint32_t i = 0; i < n; ++i) out[i] = r.sample(); }
 void orc_counter_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n_dims, float* out) {
   uint32_t k = path_key(seed, pixel, sample);

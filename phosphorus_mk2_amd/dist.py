@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing: one process per GPU, tiles interleaved over the ranks, ONE film collective.
+
+The reference has a single parallelism strategy — data parallelism over image tiles through a shared
+atomic tile cursor (src/jobs/tiles.hpp:40-47, src/xpu/cpu.cpp:223-238).  Across GPUs the cursor becomes
+a static interleave (tile i -> rank i % world: deterministic, and with the counter-based sampler the
+image does not depend on the GPU count), every rank accumulates into its own zero-initialised film and
+the films are summed onto rank 0 with one reduce — `backend="nccl"` is RCCL over xGMI on ROCm; the
+same code runs on `gloo` for the CPU tests.  Disjoint tiles make the sum exact (x + 0).
+"""
+import os
+
+
+def shard_tiles(width, height, tile_size, rank, world):
+    """The tiles of job::tiles_t::make (src/jobs/tiles.hpp:49-89) that belong to `rank`."""
+    out = []
+    i = 0
+    for y in range(0, height, tile_size):
+        for x in range(0, width, tile_size):
+            if i % world == rank:
+                out.append((x, y, min(tile_size, width - x), min(tile_size, height - y)))
+            i += 1
+    return out
+
+
+def init_process_group(backend, rank, world, device=None):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def reduce_film(film, dst=0):
+    """The single collective of a frame: sum the per-rank films onto rank `dst` (in place)."""
+    import torch.distributed as dist
+    dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    return film
+
+
+def max_over_ranks(value, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,48 @@
+"""Generates tests/golden/ref_subset_vectors.npz from oracle/_ref/libphx_ref_subset.so — object code
+compiled from the reference's own dependency-free headers (src/math/fresnel.hpp, src/math/trigonometry.hpp,
+src/math/simd/float8.hpp, src/utils/compiler.hpp) where they lie under /root/reference.  These are the only
+vectors that pin the oracle to outputs of the reference itself; run here (the reference never travels):
+
+    make -C oracle ref && python tests/golden/make_ref_subset_vectors.py
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libphx_ref_subset.so"))
+f32p = C.POINTER(C.c_float)
+fp = lambda a: a.ctypes.data_as(f32p)
+rng = np.random.default_rng(20261003)
+
+n = 2048
+cosi = rng.uniform(-1, 1, n).astype(np.float32)
+eta = rng.choice(np.array([0.0, 0.5, 1.0, 1.1, 1.33, 1.5, 2.4, 0.75], np.float32), n)
+cosi[:6] = [0.0, 1.0, -1.0, 1e-8, -1e-8, 0.5]
+fres = np.zeros(n, np.float32)
+lib.ref_fresnel_dielectric(n, fp(cosi), fp(eta), fp(fres))
+deg = rng.uniform(-720, 720, 256).astype(np.float32)
+rad = np.zeros(256, np.float32)
+lib.ref_radians(256, fp(deg), fp(rad))
+
+# simd::select(m, l, r) and compares on one 8-wide vector each
+l = rng.normal(size=(64, 8)).astype(np.float32); r = rng.normal(size=(64, 8)).astype(np.float32)
+l[0, :4] = [0.0, -0.0, np.nan, 1.0]; r[0, :4] = [-0.0, 0.0, 1.0, np.nan]
+mask = (rng.integers(0, 2, (64, 8)).astype(np.uint32) * np.uint32(0xffffffff)).view(np.float32)
+sel = np.zeros((64, 8), np.float32); cmp = np.zeros((4, 64, 8), np.float32); mm = np.zeros((2, 64, 8), np.float32)
+for i in range(64):
+    lib.ref_select8(fp(mask[i]), fp(l[i]), fp(r[i]), fp(sel[i]))
+    for op in range(4):
+        lib.ref_cmp8(op, fp(l[i]), fp(r[i]), fp(cmp[op, i]))
+    for k in range(2):
+        lib.ref_minmax8(k, fp(l[i]), fp(r[i]), fp(mm[k, i]))
+lib.ref_bscf.restype = C.c_uint64
+lib.ref_bscf.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+bs_in = rng.integers(1, 2 ** 62, 64).astype(np.uint64); bs_idx = np.zeros(64, np.uint64); bs_rest = np.zeros(64, np.uint64)
+for i in range(64):
+    rest = C.c_uint64()
+    bs_idx[i] = lib.ref_bscf(int(bs_in[i]), C.byref(rest)); bs_rest[i] = rest.value
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_subset_vectors.npz"), cosi=cosi, eta=eta, fresnel=fres, deg=deg, rad=rad,
+                    l=l, r=r, mask=mask, select=sel, cmp=cmp.view(np.uint32), minmax=mm, bscf_in=bs_in, bscf_idx=bs_idx, bscf_rest=bs_rest)
+print("wrote ref_subset_vectors.npz")

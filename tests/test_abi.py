@@ -1,0 +1,89 @@
+"""The C-ABI library loads on a box without a GPU, exports every symbol include/phx_xpu.h declares, its
+struct layouts match the ctypes mirror, and — with no device — every compute entry point fails loudly
+(no CPU fallback).  No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from phosphorus_mk2_amd import xpu
+    if not os.path.exists(xpu.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return xpu.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    from phosphorus_mk2_amd import abi
+    hdr = open(os.path.join(ROOT, "include", "phx_xpu.h")).read()
+    declared = set(re.findall(r"\b(phx_[a-z_]+)\s*\(", hdr)) - {"phx_next_tile_fn", "phx_add_tile_fn"}
+    assert declared == set(abi.EXPORTS), declared ^ set(abi.EXPORTS)
+    raw = C.CDLL(os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip.so"))
+    for s in declared:
+        assert hasattr(raw, s), s
+
+
+def test_struct_layouts(lib):
+    from phosphorus_mk2_amd import abi
+    for i, t in enumerate([abi.Options, abi.Lobe, abi.Material, abi.FaceSet, abi.Mesh, abi.Camera, abi.Scene, abi.Tile, abi.Frame, abi.Stats]):
+        assert C.sizeof(t) == lib.phx_abi_sizeof(i), t.__name__
+
+
+def test_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C99 with no C++ / torch types"""
+    import subprocess
+    src = '#include "phx_xpu.h"\nint main(void){ phx_options o; (void)o; return (int)sizeof(phx_scene) == 0; }\n'
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                   input=src.encode(), check=True)
+
+
+def test_tile_queue_matches_reference_layout(lib):
+    """job::tiles_t::make (src/jobs/tiles.hpp:49-89): row-major 32x32 tiles with edge remainders; rank/world shard."""
+    from phosphorus_mk2_amd import dist, xpu
+    q = xpu.Tiles.make(1280, 720, 32)
+    assert len(q) == 40 * 23
+    tiles = []
+    while True:
+        t = q.next()
+        if t is None:
+            break
+        tiles.append(t)
+    assert tiles[0] == (0, 0, 32, 32) and tiles[39] == (1248, 0, 32, 32) and tiles[-1] == (1248, 704, 32, 16)
+    assert tiles == dist.shard_tiles(1280, 720, 32, 0, 1)
+    assert q.next() is None
+    q.reset()
+    assert q.next() == (0, 0, 32, 32)
+    for world in (2, 3, 8):
+        got = []
+        for r in range(world):
+            qr = xpu.Tiles.make(100, 70, 32, r, world)
+            mine = []
+            while (t := qr.next()) is not None:
+                mine.append(t)
+            assert mine == dist.shard_tiles(100, 70, 32, r, world)
+            got += mine
+        assert sorted(got) == sorted(dist.shard_tiles(100, 70, 32, 0, 1))  # a partition of the film
+    with pytest.raises(xpu.DeviceError):
+        xpu.Tiles.make(64, 64, 32, rank=2, world=2)
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a visible MI355X the device cannot be made; nothing renders on the host instead."""
+    from phosphorus_mk2_amd import xpu
+    n = C.c_int(-1)
+    o = xpu.Options().pack()
+    rc = lib.phx_discover(C.byref(o), C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible: covered by the -m gpu tests")
+    assert n.value == 0 and rc != 0 and lib.phx_last_error()
+    with pytest.raises(xpu.DeviceError):
+        xpu.HipDevice.make(xpu.Options())
+    o.host_only = 1
+    assert lib.phx_discover(C.byref(o), C.byref(n)) == 0 and n.value == 0  # --no-gpu is not an error
+    assert lib.phx_dev_preprocess(None, None) != 0 and lib.phx_dev_join(None) != 0

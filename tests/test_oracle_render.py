@@ -1,0 +1,68 @@
+"""Image-level checks of the oracle (CPU only): reference-order RNG vs counter RNG agree statistically,
+thread count / tile subsets / literal-vs-conservative slab test do not change the counter-mode image,
+and the committed regression film still reproduces."""
+import os
+
+import numpy as np
+
+from conftest import ROOT, bits_equal
+
+
+def test_sequential_and_counter_modes_agree_statistically(orc):
+    from phosphorus_mk2_amd import scenes
+    O = orc.Oracle(scenes.cornell(64, 64), spp=64)
+    a, sa = O.render(rng=orc.RNG_SEQ)
+    b, sb = O.render(rng=orc.RNG_COUNTER, seed=11, threads=8)
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    # same estimator, different random numbers: block means agree to Monte-Carlo noise
+    blk = lambda f: np.clip(f[..., :3], 0, 4).reshape(8, 8, 8, 8, 3).mean(axis=(1, 3))
+    rel = np.abs(blk(a) - blk(b)) / (0.5 * (blk(a) + blk(b)) + 0.02)
+    assert rel.mean() < 0.08
+    for k in ("rays_closest", "rays_shadow", "rays_masked"):
+        assert abs(sa[k] / sb[k] - 1) < 0.02
+
+
+def test_counter_mode_is_independent_of_threads_tiles_and_slab_mode(orc):
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(2000, width=96, height=80)
+    O = orc.Oracle(sc, spp=4)
+    a, sa = O.render(rng=orc.RNG_COUNTER, seed=5, threads=1)
+    b, sb = O.render(rng=orc.RNG_COUNTER, seed=5, threads=8)
+    assert bits_equal(a, b) and sa["rays_closest"] == sb["rays_closest"]
+    c, _ = O.render(rng=orc.RNG_COUNTER, seed=5, threads=4, slab_literal=1)
+    assert bits_equal(a, c)
+    tiles = [(32, 0, 32, 32), (64, 64, 32, 16)]
+    d, _ = O.render(rng=orc.RNG_COUNTER, seed=5, threads=2, tiles=tiles)
+    for (x, y, w, h) in tiles:
+        assert bits_equal(d[y:y + h, x:x + w], a[y:y + h, x:x + w])
+    assert d[0:32, 0:32].max() == 0  # tiles not requested stay untouched
+    e, _ = O.render(rng=orc.RNG_COUNTER, seed=6, threads=8)
+    assert not bits_equal(a, e)
+
+
+def test_sample_range_partitions_the_estimate(orc):
+    """render(samples [0,2)) + render(samples [2,4)) == render(all 4) up to fp32 re-association."""
+    from phosphorus_mk2_amd import scenes
+    O = orc.Oracle(scenes.cornell(32, 32), spp=4)
+    full, _ = O.render(rng=orc.RNG_COUNTER, seed=3, threads=4)
+    lo, _ = O.render(rng=orc.RNG_COUNTER, seed=3, threads=4, sample_begin=0, sample_end=2)
+    hi, _ = O.render(rng=orc.RNG_COUNTER, seed=3, threads=4, sample_begin=2, sample_end=4)
+    assert np.allclose(lo + hi, full, rtol=1e-6, atol=1e-7)
+
+
+def test_paths_per_sample_only_scales(orc):
+    """SURVEY A-3: pps only multiplies the film by 1/pps (src/xpu/cpu.cpp:191)."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.cornell(32, 32)
+    a, _ = orc.Oracle(sc, spp=4, pps=1).render(rng=orc.RNG_COUNTER, seed=3, threads=4)
+    b, _ = orc.Oracle(sc, spp=4, pps=4).render(rng=orc.RNG_COUNTER, seed=3, threads=4)
+    assert np.allclose(a / 4, b, rtol=1e-6)
+
+
+def test_regression_film(orc):
+    """tests/golden/oracle_cornell_32x32_spp4.npy: written by tests/golden/make_oracle_pins.py from THIS
+    oracle (a regression pin, not a reference-derived vector)."""
+    from phosphorus_mk2_amd import scenes
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "oracle_cornell_32x32_spp4.npy"))
+    a, _ = orc.Oracle(scenes.cornell(32, 32), spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=2)
+    assert bits_equal(a[..., :3], ref)
