@@ -165,10 +165,10 @@ typedef struct phx_stats {
   uint64_t rays_shadow;      /* non-masked shadow rays traced */
   uint64_t rays_masked;      /* shadow rays masked before trace (src/kernels/cpu/spt.hpp:138-141) */
   uint64_t tiles;
-  uint64_t trace_launches;   /* closest + any-hit kernel launches */
-  double   trace_ms;         /* sum of HIP-event durations of the trace kernels (closest + shadow) */
-  double   closest_ms;
-  double   shadow_ms;
+  uint64_t trace_launches;   /* k_trace launches (each traces closest-hit + pending shadow rays) */
+  double   trace_ms;         /* sum of HIP-event durations of the k_trace launches */
+  double   closest_ms;       /* = trace_ms (kept for ABI stability) */
+  double   shadow_ms;        /* 0: shadow rays are traced inside k_trace */
   double   shade_ms;         /* generate + shade/NEE + integrate + film kernels */
   double   frame_ms;         /* wall time start..join on the host */
   uint64_t bvh_nodes;

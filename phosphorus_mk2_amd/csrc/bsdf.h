@@ -236,8 +236,11 @@ PHX_HD float oren_nayar_f_local(const DevLobe& p, const v3& li, const v3& lo) {
 }
 
 // eval() of src/bsdf.cpp:29-107: value (grey) and pdf of lobe p for the world-space pair (wi, wo)
+// DIFFUSE_ONLY: every lobe of every material is Lambert (decided once per scene on the host); the other
+// lobe models are compiled out, the arithmetic of the diffuse case is the same code.
+template <bool DIFFUSE_ONLY>
 PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3& wi, const v3& wo, float L5, float& pdf) {
-  switch (p.type) {
+  switch (DIFFUSE_ONLY ? (uint32_t)L_DIFFUSE : p.type) {
     case L_DIFFUSE:
       pdf = (float)((double)dot(n, wi) * kInvPiD);
       return (float)kInvPiD;
@@ -260,6 +263,7 @@ PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3&
 }
 
 // bsdf_t::f, src/bsdf.cpp:113-131
+template <bool DIFFUSE_ONLY = false>
 PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) {
   v3 out(0.0f);
   if (m.num_lobes == 0) return out;
@@ -269,7 +273,7 @@ PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) 
   for (uint32_t i = 0; i < m.num_lobes; ++i) {
     const DevLobe& p = m.lobes[i];
     float ignored;
-    const float e = lobe_eval(p, n, fr, wi, wo, m.sheen_L5, ignored);
+    const float e = lobe_eval<DIFFUSE_ONLY>(p, n, fr, wi, wo, m.sheen_L5, ignored);
     if ((reflect && (p.flags & B_REFLECT)) || (!reflect && (p.flags & B_TRANSMIT))) {
       const v3 ew = v3(e) * v3(p.wx, p.wy, p.wz);
       out = out + ew * atl;
@@ -279,6 +283,7 @@ PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) 
 }
 
 // bsdf_t::sample, src/bsdf.cpp:133-248.  Returns f (already weighted); pdf == 0 terminates.
+template <bool DIFFUSE_ONLY = false>
 PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
   pdf = 0.0f; sample_flags = 0; wo = v3(0.0f);
   const uint32_t lobes = m.num_lobes;
@@ -292,7 +297,7 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, con
   const Frame fr(n);
   float res = 0.0f;
   bool pdf_set = false;
-  switch (p.type) {
+  switch (DIFFUSE_ONLY ? (uint32_t)L_DIFFUSE : p.type) {
     case L_DIFFUSE: {
       v3 l; cosine_weighted(u, u2, l, pdf); pdf_set = true;
       wo = fr.to_world(l);
@@ -384,7 +389,7 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, con
       const bool reflect = dot(n, wi) * dot(n, wo) > 0.0f;
       if ((reflect && (q.flags & B_REFLECT)) || (!reflect && (q.flags & B_TRANSMIT))) {
         float lobe_pdf = 0.0f;
-        const float e = lobe_eval(q, n, fr, wi, wo, m.sheen_L5, lobe_pdf);
+        const float e = lobe_eval<DIFFUSE_ONLY>(q, n, fr, wi, wo, m.sheen_L5, lobe_pdf);
         result = result + v3(e) * v3(q.wx, q.wy, q.wz);
         pdf += lobe_pdf;
         ++matched;

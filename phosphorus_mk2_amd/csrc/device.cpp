@@ -303,6 +303,12 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
   sc.width = s->camera.film_width; sc.height = s->camera.film_height;
   sc.max_depth = d->opt.path_depth;
   sc.stack_levels = bvh.depth;
+  {
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, d->hip_device));
+    sc.num_cus = (uint32_t)prop.multiProcessorCount;
+  }
+  sc.diffuse_only = 1;
+  for (auto& m : mats) for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0;
   d->num_materials = s->num_materials;
   d->bvh_nodes = bvh.nodes.size();
   d->bvh_bytes = bvh.nodes.size() * sizeof(Node8) + bvh.tris.size() * sizeof(TriRec);
@@ -505,12 +511,12 @@ int phx_device::run_frame() {
   HIPCHK(hipStreamSynchronize(stream));
   DevStats ds;
   HIPCHK(hipMemcpy(&ds, dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
-  stats.camera_samples = ds.camera_samples; stats.rays_closest = ds.rays_closest; stats.rays_shadow = ds.rays_shadow; stats.rays_masked = ds.rays_masked;
+  stats.camera_samples = ds.camera_samples; stats.rays_closest = ds.rays_closest; stats.rays_shadow = ds.rays_shadow;
+  stats.rays_masked = ds.rays_closest - ds.rays_shadow;  // every shaded slot is a shadow ray or a masked slot (spt.hpp:138-141)
   for (auto& te : timed) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));
-    if (te.second == 0) { stats.closest_ms += ms; stats.trace_launches++; }
-    else if (te.second == 1) { stats.shadow_ms += ms; stats.trace_launches++; }
+    if (te.second == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
     else stats.shade_ms += ms;
   }
   stats.trace_ms = stats.closest_ms + stats.shadow_ms;
@@ -569,11 +575,13 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     if ((rc = timed_launch(2, [&]() { launch_generate(stream, scene, B, s0, ns); }))) return rc;
     int q = 0;
     for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
-      if ((rc = timed_launch(0, [&]() { launch_trace_closest(stream, scene, B, q, cap); }))) return rc;
-      if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, cap, s0); }))) return rc;
-      if ((rc = timed_launch(1, [&]() { launch_trace_shadow(stream, scene, B, cap); }))) return rc;
+      // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
+      const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
+      if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap); }))) return rc;
+      if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0); }))) return rc;
       q ^= 1;
     }
+    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;
     if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
     HIPCHK(hipGetLastError());
   }

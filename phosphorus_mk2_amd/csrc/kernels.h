@@ -37,9 +37,12 @@ struct DevScene {
   uint32_t width, height;
   uint32_t max_depth;
   uint32_t stack_levels;          // BVH depth
+  uint32_t num_cus;               // compute units of the device (persistent grid sizing)
+  uint32_t diffuse_only;          // every lobe of every material is Lambert: k_shade<true>
 };
 
-enum { CNT_IN = 0, CNT_OUT = 1, CNT_SHADOW = 2, CNT_WORDS = 8 };
+// counters: [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity)
+enum { CNT_SHADOW = 2, CNT_WORDS = 8 };
 struct DevStats { unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples; };
 
 struct PassBuffers {
@@ -61,9 +64,10 @@ struct PassBuffers {
 
 // launches (all asynchronous on `stream`)
 void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples);
-void launch_trace_closest(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity);
-void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity, uint32_t sample0);
-void launch_trace_shadow(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t capacity);
+// one persistent launch: closest-hit rays of queue q (do_closest) + any-hit rays of shadow queue sq (do_shadow)
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity);
+// shades queue q, appends survivors to queue q^1 and NEE rays to shadow queue sq
+void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0);
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);
 void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width);
 

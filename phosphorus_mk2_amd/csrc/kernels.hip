@@ -10,6 +10,9 @@
 //   k_film      the per-sample film add of tile_renderer_t::render_tile (src/xpu/cpu.cpp:175-198)
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace phx {
 
 #define PHX_BLOCK 256
@@ -17,26 +20,24 @@ namespace phx {
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
-// XCD-aware block -> work-chunk map: blocks b and b+8 share an XCD (L2), so give each XCD a
-// contiguous eighth of the live queue instead of every eighth block.
-__device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t count) {
-  const uint32_t nblk = (count + PHX_BLOCK - 1) / PHX_BLOCK;
-  const uint32_t per = (nblk + 7u) >> 3;
-  const uint32_t chunk = blockIdx.x >> 3;
-  if (chunk >= per) return 0xffffffffu / PHX_BLOCK;  // beyond this XCD's share: the caller's bound check exits
-  return (blockIdx.x & 7u) * per + chunk;
-}
-
-// append-slot allocation for the lanes of a wave that `want` one: one atomic per wave
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
+// Stream compaction: append-slot allocation for the threads of a workgroup that `want` one.
+// __ballot/__popcll give the rank inside the wave, the waves' counts are summed through LDS, and ONE
+// global atomic per workgroup reserves the slots (a returning atomic on one address sustains only
+// ~90 ops/us chip-wide — per-wave atomics made k_shade atomic-bound).  All threads of the block must call.
+#define PHX_SHADE_BLOCK 512
+__device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, uint32_t* lds /* [2 * waves + 2] */, int which) {
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = PHX_SHADE_BLOCK >> 6;
   const unsigned long long mask = __ballot(want);
-  if (!want) return 0;
-  const uint32_t lane = __lane_id();
-  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = __shfl(base, (int)leader);
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t* cnt = lds + which * (nwaves + 1);
+  if (lane == 0) cnt[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = cnt[w]; cnt[w] = total; total += c; }
+    cnt[nwaves] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  return cnt[nwaves] + cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
 // ---- generate -------------------------------------------------------------------------------------
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_generate(DevScene sc, PassBuffers
   const uint32_t path = blockIdx.x * PHX_BLOCK + threadIdx.x;
   const uint32_t npaths = pb.num_pixels * num_samples;
   if (path == 0) {
-    pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0;
+    pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + 1] = 0;
     atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
   }
   if (path >= npaths) return;
@@ -84,41 +85,132 @@ struct LdsStack {
   __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
-template <int LEVELS>
-__global__ void __launch_bounds__(PHX_BLOCK) k_trace_closest(DevScene sc, PassBuffers pb, int q) {
-  __shared__ uint2 lds[LEVELS * PHX_BLOCK];
-  const uint32_t count = pb.counters[q];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    pb.counters[q ^ 1] = 0; pb.counters[CNT_SHADOW] = 0;
-    atomicAdd(&pb.stats->rays_closest, (unsigned long long)count);
+// ---- wave-level streaming traversal -------------------------------------------------------------------
+// A wave64 that runs one ray per lane to completion wastes most of its lanes: ray lengths differ widely
+// (measured: ~20 % VALU lane utilisation with the plain per-lane loop).  Here every lane is a small state
+// machine and the wave iterates "one node visit, one triangle test, pop/finish" with all lanes in whatever
+// state they are in; a lane whose ray has finished is REFILLED from the workgroup's range of the queue as
+// soon as REFILL_MIN lanes are idle (cursor in LDS: one ds_add per refill, no global atomics).
+// Visiting order, box test and triangle test are those of traverse8 (bvh8.h), so results are identical.
+#define PHX_REFILL_MIN 16
+
+template <bool ANY, int LEVELS>
+__device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, const float4* __restrict__ qo,
+                                             const float4* __restrict__ qd, uint32_t hi, uint32_t* cursor, uint2* stack_base, uint32_t refill_min) {
+  const uint32_t lane = __lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  bool active = false, more = true;
+  RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
+  float tbest = 0.f, hu = 0.f, hv = 0.f;
+  uint32_t htri = 0xffffffffu, idx = 0, ng_base = 0, ng_hits = 0, tb = 0, th = 0;
+  float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);  // ANY: (path bits in .w of the origin record)
+  int sp = 0;
+  for (;;) {
+    // ---- refill idle lanes from the workgroup's cursor
+    const unsigned long long idle = __ballot(!active);
+    if (more && (uint32_t)__popcll(idle) >= refill_min) {
+      const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(idle));
+      base = __shfl(base, (int)leader);
+      if (base >= hi) more = false;
+      if (!active) {
+        const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
+        if (my < hi) {
+          const float4 a = qo[my], b = qd[my];
+          r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+          tbest = b.w; hu = 0.f; hv = 0.f; htri = 0xffffffffu; idx = my; extra = a;
+          ng_base = 0; ng_hits = 0x80000000u; tb = 0; th = 0; sp = 0;
+          active = true;
+        }
+      }
+    }
+    if (!__ballot(active)) break;
+    if (active) {
+      // ---- one node visit
+      if (th == 0 && ng_hits > 0x00ffffffu) {
+        const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
+        const uint32_t rest = ng_hits & ~(1u << bit);
+        if (rest > 0x00ffffffu) { stack_base[sp * PHX_BLOCK] = make_uint2(ng_base, rest); ++sp; }
+        const uint32_t slot = (bit - 24u) ^ r.oct_inv;
+        const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
+        uint32_t w[20];
+        const uint4* s4 = reinterpret_cast<const uint4*>(sc.nodes + (size_t)ni * 20u);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+        const uint32_t hm = node_hitmask(w, r, tbest);
+        ng_base = w[4];
+        ng_hits = (hm & 0xff000000u) | (w[3] >> 24);
+        tb = w[5];
+        th = hm & 0x00ffffffu;
+      }
+      // ---- one triangle test
+      if (th != 0) {
+        const uint32_t k = 31u - (uint32_t)__clz((int)th);
+        th &= ~(1u << k);
+        const TriRec T = sc.tris[tb + k];
+        float us, vs, ds;
+        if (mt_intersect(T, r.o, r.d, tbest, us, vs, ds)) {
+          tbest = ds; hu = us; hv = vs; htri = tb + k;
+          if (ANY) active = false;  // occluded: nothing to add
+        }
+      }
+      // ---- pop the next group, or finish the ray
+      if (active && th == 0 && ng_hits <= 0x00ffffffu) {
+        if (sp == 0) {
+          if (ANY) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
+            const uint32_t path = f2u(extra.w);
+            const float4 cc = pb.sc[idx];
+            float4 rr = pb.pr[path];
+            rr.x += cc.x; rr.y += cc.y; rr.z += cc.z;
+            pb.pr[path] = rr;
+          } else {
+            pb.hit[idx] = make_float4(tbest, hu, hv, u2f(htri));
+          }
+          active = false;
+        } else {
+          --sp;
+          const uint2 e = stack_base[sp * PHX_BLOCK];
+          ng_base = e.x; ng_hits = e.y;
+        }
+      }
+    }
   }
-  const uint32_t i = xcd_chunked_block(count) * PHX_BLOCK + threadIdx.x;
-  if (i >= count) return;
-  const float4 a = pb.ro[q][i], b = pb.rd[q][i];
-  LdsStack<LEVELS> st{lds + threadIdx.x, 0};
-  Hit h;
-  traverse8<false>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
-  pb.hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri));
 }
 
+// Trace kernel: closest-hit rays of ray queue `q` (if do_closest) and any-hit rays of the shadow queue `sq`
+// filled by the previous k_shade (if do_shadow) in ONE launch, so that late bounces with few rays still fill
+// the chip.  Queue lengths are only known on the device: the grid is a fixed multiple of the resident
+// workgroups and every workgroup owns one contiguous range of each queue.  The split is XCD-aware:
+// workgroups b, b+8, ... share an XCD and its L2, so each XCD gets a contiguous eighth of the queue.
 template <int LEVELS>
-__global__ void __launch_bounds__(PHX_BLOCK) k_trace_shadow(DevScene sc, PassBuffers pb) {
+__global__ void __launch_bounds__(PHX_BLOCK) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min) {
   __shared__ uint2 lds[LEVELS * PHX_BLOCK];
-  const uint32_t count = pb.counters[CNT_SHADOW];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats->rays_shadow, (unsigned long long)count);
-  const uint32_t i = xcd_chunked_block(count) * PHX_BLOCK + threadIdx.x;
-  if (i >= count) return;
-  const float4 a = pb.so[i], b = pb.sd[i];
-  LdsStack<LEVELS> st{lds + threadIdx.x, 0};
-  Hit h;
-  const bool occluded = traverse8<true>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
-  if (!occluded) {  // out += beta * li   (spt.hpp:184-186); one shadow ray per path and step: no atomics
-    const uint32_t path = f2u(a.w);
-    const float4 c = pb.sc[i];
-    float4 r = pb.pr[path];
-    r.x += c.x; r.y += c.y; r.z += c.z;
-    pb.pr[path] = r;
+  __shared__ uint32_t cursor[2];
+  const uint32_t n_closest = do_closest ? pb.counters[q] : 0u;
+  const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq] : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the queues k_shade will append to next: the other ray queue and the other shadow queue
+    if (do_closest) { pb.counters[q ^ 1] = 0; pb.counters[CNT_SHADOW + (sq ^ 1)] = 0; }
+    if (n_closest) atomicAdd(&pb.stats->rays_closest, (unsigned long long)n_closest);
+    if (n_shadow) atomicAdd(&pb.stats->rays_shadow, (unsigned long long)n_shadow);
   }
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  // this workgroup's range of a queue of n rays: XCD share, then an equal slice of it, in 64-ray units
+  auto range = [&](uint32_t n, uint32_t& lo, uint32_t& hi) {
+    const uint32_t chunks = (n + 63u) >> 6, per_xcd = (chunks + 7u) >> 3, per_slot = (per_xcd + nslots - 1u) / nslots;
+    const uint32_t c0 = min(xcd * per_xcd + slot * per_slot, chunks);
+    const uint32_t c1 = min(min(xcd * per_xcd + (slot + 1u) * per_slot, (xcd + 1u) * per_xcd), chunks);
+    lo = c0 << 6; hi = min(c1 << 6, n);
+    if (hi < lo) hi = lo;
+  };
+  uint32_t slo, shi, clo, chi;
+  range(n_shadow, slo, shi);
+  range(n_closest, clo, chi);
+  if (threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
+  __syncthreads();
+  if (shi > slo) trace_stream<true, LEVELS>(sc, pb, pb.so, pb.sd, shi, &cursor[0], lds + threadIdx.x, refill_min);
+  if (chi > clo) trace_stream<false, LEVELS>(sc, pb, pb.ro[q], pb.rd[q], chi, &cursor[1], lds + threadIdx.x, refill_min);
 }
 
 template <int LEVELS, bool ANY>
@@ -148,9 +240,12 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
   return (float)0.212671 * c.x + (float)0.715160 * c.y + (float)0.072169 * c.z;
 }
 
-__global__ void __launch_bounds__(PHX_BLOCK) k_shade(DevScene sc, PassBuffers pb, int q, uint32_t sample0) {
+template <bool DIFFUSE_ONLY>
+__global__ void __launch_bounds__(PHX_SHADE_BLOCK) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+  __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q];
-  const uint32_t i = blockIdx.x * PHX_BLOCK + threadIdx.x;
+  const uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
+  if (blockIdx.x * PHX_SHADE_BLOCK >= count) return;
   const bool live = i < count;
   bool alive = false, want_shadow = false, masked = false;
   uint32_t path = 0, next_specular = 0;
@@ -206,7 +301,7 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_shade(DevScene sc, PassBuffers pb
         wl = v3(wl.x * oolen, wl.y * oolen, wl.z * oolen);
         if (sdot(n, wl) >= 0.0f) {
           // li(), spt.hpp:212-255 — evaluated before the occlusion test; added by k_trace_shadow if unoccluded
-          const v3 f = bsdf_f(m, n, wl, wo);
+          const v3 f = bsdf_f<DIFFUSE_ONLY>(m, n, wl, wo);
           const uint32_t lpm = sc.prim_material[LT.prim];
           const v3 ln = shading_normal(sc, LT.prim, (lpm >> 31) != 0, lb - la, lc - la, bu, bv);
           const DevMaterial& lm = sc.materials[L.material];
@@ -234,7 +329,7 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_shade(DevScene sc, PassBuffers pb
       if (alive) {
         const uint32_t b1 = (depth - 1u) * DIMS_PER_STEP;
         v3 sampled; float pdf; uint32_t fl;
-        const v3 f = bsdf_sample(m, n, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, sampled, pdf, fl);
+        const v3 f = bsdf_sample<DIFFUSE_ONLY>(m, n, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, sampled, pdf, fl);
         if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) {
           alive = false;
         } else {
@@ -257,19 +352,18 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_shade(DevScene sc, PassBuffers pb
     pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
   }
   // ---- stream compaction: survivors -> next ray queue, unmasked NEE rays -> shadow queue
-  const uint32_t no = wave_append(alive, &pb.counters[q ^ 1]);
+  const uint32_t no = block_append(alive, &pb.counters[q ^ 1], lds_cnt, 0);
   if (alive) {
     pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
     pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
   }
-  const uint32_t ns = wave_append(want_shadow, &pb.counters[CNT_SHADOW]);
+  const uint32_t ns = block_append(want_shadow, &pb.counters[CNT_SHADOW + sq], lds_cnt, 1);
   if (want_shadow) {
     pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
     pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
     pb.sc[ns] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
   }
-  const unsigned long long mm = __ballot(masked);
-  if (mm && __lane_id() == (uint32_t)__ffsll((long long)mm) - 1u) atomicAdd(&pb.stats->rays_masked, (unsigned long long)__popcll(mm));
+  (void)masked;  // rays_masked = rays_closest - rays_shadow: every shaded slot yields a shadow ray or a masked slot
 }
 
 // ---- film -------------------------------------------------------------------------------------------
@@ -322,27 +416,28 @@ __global__ void k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n
 
 // ---- launches ---------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n) { return (n + PHX_BLOCK - 1) / PHX_BLOCK; }
-// XCD-chunked kernels index past the plain block count when it is not a multiple of 8
-static inline uint32_t blocks_for_chunked(uint32_t n) { uint32_t b = blocks_for(n); return ((b + 7u) / 8u) * 8u; }
-
 void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples) {
   const uint32_t npaths = pb.num_pixels * num_samples;
   hipLaunchKernelGGL(k_generate, dim3(blocks_for(npaths)), dim3(PHX_BLOCK), 0, stream, sc, pb, sample0, num_samples);
 }
-void launch_trace_closest(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity) {
-  const dim3 g(blocks_for_chunked(capacity)), b(PHX_BLOCK);
-  if (sc.stack_levels <= 12) hipLaunchKernelGGL(k_trace_closest<12>, g, b, 0, stream, sc, pb, q);
-  else if (sc.stack_levels <= 24) hipLaunchKernelGGL(k_trace_closest<24>, g, b, 0, stream, sc, pb, q);
-  else hipLaunchKernelGGL(k_trace_closest<64>, g, b, 0, stream, sc, pb, q);
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity) {
+  // persistent grid: resident workgroups only (LDS-limited: 160 KB / (LEVELS * 2 KB)), a multiple of 8 (XCDs)
+  const uint32_t levels = sc.stack_levels <= 12 ? 12u : (sc.stack_levels <= 24 ? 24u : 64u);
+  const uint32_t per_cu = std::max(1u, std::min(8u, 160u / (levels * 2u)));
+  static const int gmul = getenv("PHX_TRACE_GRID") ? atoi(getenv("PHX_TRACE_GRID")) : 2;
+  static const uint32_t refill = getenv("PHX_REFILL") ? (uint32_t)atoi(getenv("PHX_REFILL")) : 8u;
+  uint32_t grid = sc.num_cus * per_cu * gmul;
+  const uint32_t need = ((blocks_for(capacity) + 7u) / 8u) * 8u;
+  grid = std::max(8u, std::min(grid, need));
+  const dim3 g(grid), b(PHX_BLOCK);
+  if (levels == 12) hipLaunchKernelGGL(k_trace<12>, g, b, 0, stream, sc, pb, q, sq, do_closest, do_shadow, refill);
+  else if (levels == 24) hipLaunchKernelGGL(k_trace<24>, g, b, 0, stream, sc, pb, q, sq, do_closest, do_shadow, refill);
+  else hipLaunchKernelGGL(k_trace<64>, g, b, 0, stream, sc, pb, q, sq, do_closest, do_shadow, refill);
 }
-void launch_trace_shadow(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t capacity) {
-  const dim3 g(blocks_for_chunked(capacity)), b(PHX_BLOCK);
-  if (sc.stack_levels <= 12) hipLaunchKernelGGL(k_trace_shadow<12>, g, b, 0, stream, sc, pb);
-  else if (sc.stack_levels <= 24) hipLaunchKernelGGL(k_trace_shadow<24>, g, b, 0, stream, sc, pb);
-  else hipLaunchKernelGGL(k_trace_shadow<64>, g, b, 0, stream, sc, pb);
-}
-void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t capacity, uint32_t sample0) {
-  hipLaunchKernelGGL(k_shade, dim3(blocks_for(capacity)), dim3(PHX_BLOCK), 0, stream, sc, pb, q, sample0);
+void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0) {
+  const dim3 g((capacity + PHX_SHADE_BLOCK - 1) / PHX_SHADE_BLOCK), b(PHX_SHADE_BLOCK);
+  if (sc.diffuse_only) hipLaunchKernelGGL(k_shade<true>, g, b, 0, stream, sc, pb, q, sq, sample0);
+  else hipLaunchKernelGGL(k_shade<false>, g, b, 0, stream, sc, pb, q, sq, sample0);
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
   hipLaunchKernelGGL(k_film, dim3(blocks_for(pb.num_pixels)), dim3(PHX_BLOCK), 0, stream, pb, num_samples, inv);
