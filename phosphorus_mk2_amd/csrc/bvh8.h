@@ -22,7 +22,8 @@ struct alignas(16) Node8 {
   uint8_t ex, ey, ez, imask;  // grid scale exponents (biased like fp32), bit i of imask: child slot i is an inner node
   uint32_t child_base;        // index of this node's first inner child (children are contiguous, in slot order)
   uint32_t tri_base;          // index of this node's first triangle record
-  uint8_t meta[8];            // inner: 0b001_11sss (24+slot); leaf: unary count <<5 | first triangle offset; empty: 0
+  uint32_t tmask;             // bit (s + 8*j), j < 3: leaf slot s holds a j-th triangle; records are stored in bit order
+  uint32_t pad;
   uint8_t qlox[8], qloy[8], qloz[8], qhix[8], qhiy[8], qhiz[8];
 };
 static_assert(sizeof(Node8) == 80, "Node8 must be five 16-byte words");
@@ -31,8 +32,9 @@ struct TriRec {  // 48 B: three 16-byte words
   float v0x, v0y, v0z, e0x;
   float e0y, e0z, e1x, e1y;
   float e1z;
-  uint32_t prim;  // index in scene_t::triangles() order
-  uint32_t pad0, pad1;
+  uint32_t prim;      // index in scene_t::triangles() order
+  uint32_t material;  // material | smooth << 31 (filled by the device after the build: saves k_shade a dependent load)
+  uint32_t pad1;
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be three 16-byte words");
 
@@ -89,18 +91,26 @@ PHX_HD RayCtx make_ray_ctx(const v3& o, const v3& d) {
   return r;
 }
 
-PHX_HD uint32_t node_hitmask(const uint32_t* w /* 20 words of the node */, const RayCtx& r, float tmax) {
+// XOR-permutation of the low 8 bits of x: bit i moves to bit (i ^ oct), oct in [0,8)
+PHX_HD uint32_t perm_xor8(uint32_t x, uint32_t oct) {
+  x = (oct & 4u) ? (((x << 4) | (x >> 4)) & 0xffu) : x;
+  x = (oct & 2u) ? (((x & 0x33u) << 2) | ((x & 0xccu) >> 2)) : x;
+  x = (oct & 1u) ? (((x & 0x55u) << 1) | ((x & 0xaau) >> 1)) : x;
+  return x;
+}
+
+// The 8 box tests of one node for one ray: bit i of the result = child slot i may be hit.
+PHX_HD uint32_t node_hit8(const uint32_t* w /* 20 words of the node */, const RayCtx& r, float tmax) {
   const float px = u32_as_f32(w[0]), py = u32_as_f32(w[1]), pz = u32_as_f32(w[2]);
   const uint32_t e = w[3];
   const float sx = u32_as_f32((e & 0xffu) << 23), sy = u32_as_f32(((e >> 8) & 0xffu) << 23), sz = u32_as_f32(((e >> 16) & 0xffu) << 23);
   const float ax = sx * r.idx, ay = sy * r.idy, az = sz * r.idz;
   const float bx = (px - r.o.x) * r.idx, by = (py - r.o.y) * r.idy, bz = (pz - r.o.z) * r.idz;
   const bool nx = r.idx < 0.0f, ny = r.idy < 0.0f, nz = r.idz < 0.0f;
-  // words: 6,7 meta | 8,9 qlox | 10,11 qloy | 12,13 qloz | 14,15 qhix | 16,17 qhiy | 18,19 qhiz
-  uint32_t hitmask = 0;
+  // words: 8,9 qlox | 10,11 qloy | 12,13 qloz | 14,15 qhix | 16,17 qhiy | 18,19 qhiz
+  uint32_t hit8 = 0;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const uint32_t meta4 = w[6 + half];
     const uint32_t nearx = nx ? w[14 + half] : w[8 + half], farx = nx ? w[8 + half] : w[14 + half];
     const uint32_t neary = ny ? w[16 + half] : w[10 + half], fary = ny ? w[10 + half] : w[16 + half];
     const uint32_t nearz = nz ? w[18 + half] : w[12 + half], farz = nz ? w[12 + half] : w[18 + half];
@@ -117,15 +127,19 @@ PHX_HD uint32_t node_hitmask(const uint32_t* w /* 20 words of the node */, const
       float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
       tn = tn - fabsf(tn) * 4.76837158203125e-7f;  // pad both ends by 4 ulp: never reject a box that holds a hit
       tf = tf + fabsf(tf) * 4.76837158203125e-7f;
-      const uint32_t meta = (meta4 >> sh) & 0xffu;
-      if (tn <= tf) {
-        const uint32_t is_inner = ((meta & 0x18u) == 0x18u) ? 7u : 0u;
-        const uint32_t bit_index = (meta & 31u) ^ (r.oct_inv & is_inner);
-        hitmask |= (meta >> 5) << bit_index;
-      }
+      if (tn <= tf) hit8 |= 1u << (4 * half + j);  // empty slots have inverted boxes (qlo 255 > qhi 0)
     }
   }
-  return hitmask;
+  return hit8;
+}
+
+// CWBVH-style hit mask of a node: inner children set bit 24 + (slot ^ oct_inv) (so that "highest bit first"
+// visits them in the ray's octant order), the triangles of hit leaf slots set their bits in [0,24).
+PHX_HD uint32_t node_hitmask(const uint32_t* w, const RayCtx& r, float tmax) {
+  const uint32_t hit8 = node_hit8(w, r, tmax);
+  const uint32_t imask = w[3] >> 24;
+  const uint32_t leaf = hit8 & ~imask;
+  return (perm_xor8(hit8 & imask, r.oct_inv) << 24) | ((leaf | (leaf << 8) | (leaf << 16)) & w[6]);
 }
 
 // Closest-hit (ANY=false) or any-hit (ANY=true) traversal of one ray.  Stack: push(uint32,uint32),
@@ -161,15 +175,16 @@ PHX_HD bool traverse8(const uint32_t* __restrict__ nodes /* 20 words per node */
     ng_base = w[4];
     ng_hits = (hm & 0xff000000u) | (w[3] >> 24);
     uint32_t th = hm & 0x00ffffffu;
-    const uint32_t tb = w[5];
+    const uint32_t tb = w[5], tm = w[6];
     while (th) {
       const uint32_t k = 31u - (uint32_t)clz32(th);
       th &= ~(1u << k);
-      const TriRec T = tris[tb + k];
+      const uint32_t ti = tb + (uint32_t)popc32(tm & ~(0xffffffffu << k));
+      const TriRec T = tris[ti];
       float us, vs, ds;
       if (tri_tests) ++*tri_tests;
       if (mt_intersect(T, o, d, hit.t, us, vs, ds)) {
-        hit.t = ds; hit.u = us; hit.v = vs; hit.tri = tb + k;
+        hit.t = ds; hit.u = us; hit.v = vs; hit.tri = ti;
         if (ANY) return true;
       }
     }

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <future>
@@ -32,7 +33,7 @@ struct Node2 {
 
 const int BINS = 16;
 const int MAX_LEAF = 3;       // triangles per leaf child slot (unary count fits meta's 3 bits)
-const float C_TRAV = 0.35f;   // cost of one child-slot box test relative to one triangle test
+static float C_TRAV = 0.35f;  // cost of one child-slot box test relative to one triangle test
 
 struct Builder2 {
   const Box* pbox;
@@ -116,6 +117,7 @@ inline void slot_dir(int s, float* d) { d[0] = (s & 4) ? -1.0f : 1.0f; d[1] = (s
 }  // namespace
 
 void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads) {
+  if (const char* e = getenv("PHX_CTRAV")) C_TRAV = (float)atof(e);
   out.nodes.clear(); out.tris.clear(); out.depth = 1;
   if (n == 0) {  // a root that hits nothing
     Node8 root; std::memset(&root, 0, sizeof(root));
@@ -208,11 +210,10 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads) {
     nd.ex = eb[0]; nd.ey = eb[1]; nd.ez = eb[2];
     nd.child_base = (uint32_t)out.nodes.size();
     nd.tri_base = (uint32_t)out.tris.size();
-    uint32_t tri_off = 0;
     for (int s = 0; s < 8; ++s) {
       const int i = child_in_slot[s];
-      if (i < 0) {  // empty slot: inverted box, no meta bits
-        nd.qlox[s] = nd.qloy[s] = nd.qloz[s] = 255; nd.qhix[s] = nd.qhiy[s] = nd.qhiz[s] = 0; nd.meta[s] = 0;
+      if (i < 0) {  // empty slot: inverted box, never hit
+        nd.qlox[s] = nd.qloy[s] = nd.qloz[s] = 255; nd.qhix[s] = nd.qhiy[s] = nd.qhiz[s] = 0;
         continue;
       }
       const Node2& c = B.nodes[ch[i]];
@@ -225,25 +226,27 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads) {
         qlo[a][s] = (uint8_t)lo; qhi[a][s] = (uint8_t)hi;
       }
       if (c.count > 0) {
-        nd.meta[s] = (uint8_t)((((1u << c.count) - 1u) << 5) | tri_off);
-        for (uint32_t k = 0; k < c.count; ++k) {
-          const uint32_t p = B.idx[c.first + k];
-          const float* t = tri_abc + 9 * (size_t)p;
-          TriRec T; std::memset(&T, 0, sizeof(T));
-          T.v0x = t[0]; T.v0y = t[1]; T.v0z = t[2];
-          T.e0x = t[3] - t[0]; T.e0y = t[4] - t[1]; T.e0z = t[5] - t[2];  // e0 = b - a, e1 = c - a (triangle.hpp:48-50)
-          T.e1x = t[6] - t[0]; T.e1y = t[7] - t[1]; T.e1z = t[8] - t[2];
-          T.prim = p;
-          out.tris.push_back(T);
-        }
-        tri_off += c.count;
+        for (uint32_t k = 0; k < c.count; ++k) nd.tmask |= 1u << (s + 8 * (int)k);
       } else {
-        nd.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
         nd.imask |= (uint8_t)(1u << s);
         const uint32_t n8 = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         queue.push_back(Work{ch[i], n8, wk.depth + 1});
       }
+    }
+    // triangle records in tmask bit order: bit (s + 8*j) = j-th triangle of leaf slot s
+    for (int bit = 0; bit < 24; ++bit) {
+      if (!(nd.tmask & (1u << bit))) continue;
+      const int s = bit & 7, k = bit >> 3;
+      const Node2& c = B.nodes[ch[child_in_slot[s]]];
+      const uint32_t p = B.idx[c.first + (uint32_t)k];
+      const float* t = tri_abc + 9 * (size_t)p;
+      TriRec T; std::memset(&T, 0, sizeof(T));
+      T.v0x = t[0]; T.v0y = t[1]; T.v0z = t[2];
+      T.e0x = t[3] - t[0]; T.e0y = t[4] - t[1]; T.e0z = t[5] - t[2];  // e0 = b - a, e1 = c - a (triangle.hpp:48-50)
+      T.e1x = t[6] - t[0]; T.e1y = t[7] - t[1]; T.e1z = t[8] - t[2];
+      T.prim = p;
+      out.tris.push_back(T);
     }
     out.nodes[wk.n8] = nd;
   }

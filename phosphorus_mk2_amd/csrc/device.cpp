@@ -279,6 +279,8 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
   const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
   build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads);
 
+  for (auto& T : bvh.tris) T.material = prim_material[T.prim];
+
   int rc;
   if ((rc = d->d_nodes.upload(bvh.nodes))) return rc;
   if ((rc = d->d_tris.upload(bvh.tris))) return rc;
@@ -303,6 +305,7 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
   sc.width = s->camera.film_width; sc.height = s->camera.film_height;
   sc.max_depth = d->opt.path_depth;
   sc.stack_levels = bvh.depth;
+  sc.num_nodes = (uint32_t)bvh.nodes.size();
   {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, d->hip_device));
     sc.num_cus = (uint32_t)prop.multiProcessorCount;
@@ -577,11 +580,11 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
       // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
       const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
-      if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap); }))) return rc;
+      if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap, bounce == 0); }))) return rc;
       if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0); }))) return rc;
       q ^= 1;
     }
-    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;
+    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap, 0); }))) return rc;
     if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
     HIPCHK(hipGetLastError());
   }

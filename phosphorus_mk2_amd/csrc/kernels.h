@@ -37,6 +37,7 @@ struct DevScene {
   uint32_t width, height;
   uint32_t max_depth;
   uint32_t stack_levels;          // BVH depth
+  uint32_t num_nodes;             // Node8 count (nodes are stored breadth-first)
   uint32_t num_cus;               // compute units of the device (persistent grid sizing)
   uint32_t diffuse_only;          // every lobe of every material is Lambert: k_shade<true>
 };
@@ -65,7 +66,8 @@ struct PassBuffers {
 // launches (all asynchronous on `stream`)
 void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples);
 // one persistent launch: closest-hit rays of queue q (do_closest) + any-hit rays of shadow queue sq (do_shadow)
-void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity);
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
+                  int camera_rays);
 // shades queue q, appends survivors to queue q^1 and NEE rays to shadow queue sq
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0);
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);

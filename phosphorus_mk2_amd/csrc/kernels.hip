@@ -92,38 +92,46 @@ struct LdsStack {
 // state they are in; a lane whose ray has finished is REFILLED from the workgroup's range of the queue as
 // soon as REFILL_MIN lanes are idle (cursor in LDS: one ds_add per refill, no global atomics).
 // Visiting order, box test and triangle test are those of traverse8 (bvh8.h), so results are identical.
-#define PHX_REFILL_MIN 16
-
-template <bool ANY, int LEVELS>
-__device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, const float4* __restrict__ qo,
-                                             const float4* __restrict__ qd, uint32_t hi, uint32_t* cursor, uint2* stack_base, uint32_t refill_min) {
+// One stream serves BOTH queues: lanes are refilled from the workgroup's shadow-ray range first, then from
+// its closest-hit range; the any-hit / closest-hit distinction is a per-lane flag, so a launch has a single
+// drain phase (the tail where rays run out and lanes idle) instead of one per queue.
+template <int BLOCK>
+__device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
+                                             uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t refill_min,
+                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop) {
   const uint32_t lane = __lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  bool active = false, more = true;
+  bool active = false, any = false;
+  uint32_t phase = 0;  // wave-uniform: 0 = shadow range, 1 = closest range, 2 = drained
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
   float tbest = 0.f, hu = 0.f, hv = 0.f;
-  uint32_t htri = 0xffffffffu, idx = 0, ng_base = 0, ng_hits = 0, tb = 0, th = 0;
-  float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);  // ANY: (path bits in .w of the origin record)
+  uint32_t htri = 0xffffffffu, idx = 0, ng_base = 0, ng_hits = 0, tb = 0, th = 0, tm = 0, path = 0;
   int sp = 0;
+  const float4* __restrict__ ro = pb.ro[q];
+  const float4* __restrict__ rd = pb.rd[q];
   for (;;) {
-    // ---- refill idle lanes from the workgroup's cursor
+    // ---- refill idle lanes from the workgroup's cursors
     const unsigned long long idle = __ballot(!active);
-    if (more && (uint32_t)__popcll(idle) >= refill_min) {
+    if (phase < 2u && (uint32_t)__popcll(idle) >= refill_min) {
       const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+      const uint32_t hi = phase == 0u ? shi : chi;
       uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(idle));
+      if (lane == leader) base = atomicAdd(&cursor[phase], (uint32_t)__popcll(idle));
       base = __shfl(base, (int)leader);
-      if (base >= hi) more = false;
       if (!active) {
         const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
         if (my < hi) {
-          const float4 a = qo[my], b = qd[my];
+          float4 a, b;
+          if (phase == 0u) { a = pb.so[my]; b = pb.sd[my]; } else { a = ro[my]; b = rd[my]; }
           r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
-          tbest = b.w; hu = 0.f; hv = 0.f; htri = 0xffffffffu; idx = my; extra = a;
+          tbest = b.w; hu = 0.f; hv = 0.f; htri = 0xffffffffu; idx = my; path = f2u(a.w);
           ng_base = 0; ng_hits = 0x80000000u; tb = 0; th = 0; sp = 0;
+          any = phase == 0u;
           active = true;
         }
       }
+      if (base + (uint32_t)__popcll(idle) >= hi) ++phase;  // this range is used up (wave-uniform)
+      if (phase < 2u && __ballot(active) == 0ull) continue;  // nothing in flight yet: go fetch from the next range
     }
     if (!__ballot(active)) break;
     if (active) {
@@ -131,35 +139,41 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       if (th == 0 && ng_hits > 0x00ffffffu) {
         const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
         const uint32_t rest = ng_hits & ~(1u << bit);
-        if (rest > 0x00ffffffu) { stack_base[sp * PHX_BLOCK] = make_uint2(ng_base, rest); ++sp; }
+        if (rest > 0x00ffffffu) { stack_base[sp * BLOCK] = make_uint2(ng_base, rest); ++sp; }
         const uint32_t slot = (bit - 24u) ^ r.oct_inv;
         const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
         uint32_t w[20];
-        const uint4* s4 = reinterpret_cast<const uint4*>(sc.nodes + (size_t)ni * 20u);
+        if (ni < ntop) {  // top-of-tree nodelet staged in LDS: five ds_read_b128 instead of five L1 requests per lane
+          const uint4* s4 = top + ni * 5u;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+          for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+        } else {
+          const uint4* s4 = reinterpret_cast<const uint4*>(sc.nodes + (size_t)ni * 20u);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+        }
         const uint32_t hm = node_hitmask(w, r, tbest);
         ng_base = w[4];
         ng_hits = (hm & 0xff000000u) | (w[3] >> 24);
-        tb = w[5];
+        tb = w[5]; tm = w[6];
         th = hm & 0x00ffffffu;
       }
       // ---- one triangle test
       if (th != 0) {
         const uint32_t k = 31u - (uint32_t)__clz((int)th);
         th &= ~(1u << k);
-        const TriRec T = sc.tris[tb + k];
+        const uint32_t ti = tb + (uint32_t)__popc(tm & ~(0xffffffffu << k));
+        const TriRec T = sc.tris[ti];
         float us, vs, ds;
         if (mt_intersect(T, r.o, r.d, tbest, us, vs, ds)) {
-          tbest = ds; hu = us; hv = vs; htri = tb + k;
-          if (ANY) active = false;  // occluded: nothing to add
+          tbest = ds; hu = us; hv = vs; htri = ti;
+          if (any) active = false;  // occluded: nothing to add
         }
       }
       // ---- pop the next group, or finish the ray
       if (active && th == 0 && ng_hits <= 0x00ffffffu) {
         if (sp == 0) {
-          if (ANY) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
-            const uint32_t path = f2u(extra.w);
+          if (any) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
             const float4 cc = pb.sc[idx];
             float4 rr = pb.pr[path];
             rr.x += cc.x; rr.y += cc.y; rr.z += cc.z;
@@ -170,7 +184,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           active = false;
         } else {
           --sp;
-          const uint2 e = stack_base[sp * PHX_BLOCK];
+          const uint2 e = stack_base[sp * BLOCK];
           ng_base = e.x; ng_hits = e.y;
         }
       }
@@ -183,10 +197,14 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 // the chip.  Queue lengths are only known on the device: the grid is a fixed multiple of the resident
 // workgroups and every workgroup owns one contiguous range of each queue.  The split is XCD-aware:
 // workgroups b, b+8, ... share an XCD and its L2, so each XCD gets a contiguous eighth of the queue.
-template <int LEVELS>
-__global__ void __launch_bounds__(PHX_BLOCK) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min) {
-  __shared__ uint2 lds[LEVELS * PHX_BLOCK];
-  __shared__ uint32_t cursor[2];
+// Dynamic LDS layout: [ntop nodelets x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
+                                                 int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks) {
+  extern __shared__ uint4 smem[];
+  uint4* top = smem;
+  uint2* stack = reinterpret_cast<uint2*>(smem + ntop * 5u);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
   const uint32_t n_closest = do_closest ? pb.counters[q] : 0u;
   const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq] : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -198,19 +216,31 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_trace(DevScene sc, PassBuffers pb
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   // this workgroup's range of a queue of n rays: XCD share, then an equal slice of it, in 64-ray units
   auto range = [&](uint32_t n, uint32_t& lo, uint32_t& hi) {
-    const uint32_t chunks = (n + 63u) >> 6, per_xcd = (chunks + 7u) >> 3, per_slot = (per_xcd + nslots - 1u) / nslots;
-    const uint32_t c0 = min(xcd * per_xcd + slot * per_slot, chunks);
-    const uint32_t c1 = min(min(xcd * per_xcd + (slot + 1u) * per_slot, (xcd + 1u) * per_xcd), chunks);
+    // short queues: fewer, longer slices (at least min_chunks 64-ray chunks per workgroup) keep lanes refilled
+    // instead of spreading a handful of rays over every resident wave
+    const uint32_t chunks = (n + 63u) >> 6, per_xcd = (chunks + 7u) >> 3;
+    const uint32_t per_slot = max((per_xcd + nslots - 1u) / nslots, min_chunks);
+    uint32_t c0, c1;
+    if (interleave) {  // plain contiguous slices in launch order: image regions of different cost spread over all XCDs
+      const uint32_t per_blk = max((chunks + gridDim.x - 1u) / gridDim.x, min_chunks);
+      c0 = min(blockIdx.x * per_blk, chunks); c1 = min(c0 + per_blk, chunks);
+    } else {
+      c0 = min(xcd * per_xcd + slot * per_slot, chunks);
+      c1 = min(min(xcd * per_xcd + (slot + 1u) * per_slot, (xcd + 1u) * per_xcd), chunks);
+    }
     lo = c0 << 6; hi = min(c1 << 6, n);
     if (hi < lo) hi = lo;
   };
   uint32_t slo, shi, clo, chi;
   range(n_shadow, slo, shi);
   range(n_closest, clo, chi);
+  if (shi <= slo && chi <= clo) return;  // nothing for this workgroup (uniform)
+  // stage the top of the tree (nodes are stored breadth-first: the first ntop nodes ARE the top levels)
+  const uint4* g4 = reinterpret_cast<const uint4*>(sc.nodes);
+  for (uint32_t i = threadIdx.x; i < ntop * 5u; i += BLOCK) top[i] = g4[i];
   if (threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
   __syncthreads();
-  if (shi > slo) trace_stream<true, LEVELS>(sc, pb, pb.so, pb.sd, shi, &cursor[0], lds + threadIdx.x, refill_min);
-  if (chi > clo) trace_stream<false, LEVELS>(sc, pb, pb.ro[q], pb.rd[q], chi, &cursor[1], lds + threadIdx.x, refill_min);
+  trace_stream<BLOCK>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop);
 }
 
 template <int LEVELS, bool ANY>
@@ -267,7 +297,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) k_shade(DevScene sc, PassBuff
     const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
     if (tri != 0xffffffffu) {
       const TriRec T = sc.tris[tri];
-      const uint32_t pm = sc.prim_material[T.prim];
+      const uint32_t pm = T.material;
       const DevMaterial& m = sc.materials[pm & 0x7fffffffu];
       const v3 p = o + d * h.x;            // hits.p = p + wi*d
       const v3 wo = -d;                    // hits.wi = -wi
@@ -420,19 +450,35 @@ void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& 
   const uint32_t npaths = pb.num_pixels * num_samples;
   hipLaunchKernelGGL(k_generate, dim3(blocks_for(npaths)), dim3(PHX_BLOCK), 0, stream, sc, pb, sample0, num_samples);
 }
-void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity) {
-  // persistent grid: resident workgroups only (LDS-limited: 160 KB / (LEVELS * 2 KB)), a multiple of 8 (XCDs)
-  const uint32_t levels = sc.stack_levels <= 12 ? 12u : (sc.stack_levels <= 24 ? 24u : 64u);
-  const uint32_t per_cu = std::max(1u, std::min(8u, 160u / (levels * 2u)));
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
+                  int camera_rays) {
   static const int gmul = getenv("PHX_TRACE_GRID") ? atoi(getenv("PHX_TRACE_GRID")) : 2;
+  static const int gmul0 = getenv("PHX_TRACE_GRID0") ? atoi(getenv("PHX_TRACE_GRID0")) : 8;
+  static const int inter0 = getenv("PHX_TRACE_INTER0") ? atoi(getenv("PHX_TRACE_INTER0")) : 1;
   static const uint32_t refill = getenv("PHX_REFILL") ? (uint32_t)atoi(getenv("PHX_REFILL")) : 8u;
-  uint32_t grid = sc.num_cus * per_cu * gmul;
-  const uint32_t need = ((blocks_for(capacity) + 7u) / 8u) * 8u;
+  static const uint32_t block = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 256u;
+  static const uint32_t ntop_req = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 73u;
+  static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
+  // stack entries needed = BVH depth - 1 (one pending sibling group per level)
+  const uint32_t levels = std::max(2u, sc.stack_levels);
+  const uint32_t ntop = std::min(ntop_req, sc.num_nodes);
+  const uint32_t lds = ntop * 80u + levels * block * 8u + 16u;
+  const uint32_t wg_per_cu = std::max(1u, std::min({160u * 1024u / lds, 2048u / block, 512u * 64u * 4u / (64u * block)}));
+  const int interleave = camera_rays ? inter0 : 0;
+  uint32_t grid = sc.num_cus * wg_per_cu * (uint32_t)(camera_rays ? gmul0 : gmul);
+  const uint32_t need = (((capacity + block - 1) / block + 7u) / 8u) * 8u;
   grid = std::max(8u, std::min(grid, need));
-  const dim3 g(grid), b(PHX_BLOCK);
-  if (levels == 12) hipLaunchKernelGGL(k_trace<12>, g, b, 0, stream, sc, pb, q, sq, do_closest, do_shadow, refill);
-  else if (levels == 24) hipLaunchKernelGGL(k_trace<24>, g, b, 0, stream, sc, pb, q, sq, do_closest, do_shadow, refill);
-  else hipLaunchKernelGGL(k_trace<64>, g, b, 0, stream, sc, pb, q, sq, do_closest, do_shadow, refill);
+  const dim3 g(grid), b(block);
+  static bool attr_set = false;
+  if (!attr_set) {  // allow the full 160 KB of LDS as dynamic shared memory
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (block == 256) hipLaunchKernelGGL(k_trace<256>, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks);
+  else if (block == 512) hipLaunchKernelGGL(k_trace<512>, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks);
+  else hipLaunchKernelGGL(k_trace<1024>, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks);
 }
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0) {
   const dim3 g((capacity + PHX_SHADE_BLOCK - 1) / PHX_SHADE_BLOCK), b(PHX_SHADE_BLOCK);
