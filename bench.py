@@ -79,6 +79,23 @@ def cpu_baseline(scene, args):
     return out, visits
 
 
+def committed_traffic(args):
+    """HBM bytes per k_trace launch from the newest committed PMC summary of this workload
+    (profiles/r*_100k_pmc.json, written by scripts/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE
+    rocprofv3 passes).  bench.py cannot collect PMCs itself; a different workload reports null."""
+    import glob
+    if (args.triangles, args.width, args.height, args.depth) != (100000, 1280, 720, 9):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_100k_pmc.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, e in d["kernels"].items():
+        if k.startswith("k_trace") and "hbm_bytes_per_launch_corrected" in e:
+            return e["hbm_bytes_per_launch_corrected"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +143,7 @@ def main():
             pdist.reduce_film(film_dev, dst=0)  # the single film collective (RCCL over xGMI)
         else:
             film_host.data[:] = 0
-            dev.start(scene, xpu.FrameState(args.seed, tiles, film_host))
+            dev.start(scene, xpu.FrameState(args.seed, tiles, film_host, native_sink=True))
             dev.join()
         return dev.stats()
 
@@ -182,6 +199,9 @@ def main():
                          "launches": nl, "avg_launch_ms": acc["closest_ms"] / nl,
                          "rays_per_launch": (acc["closest"] + acc["shadow"]) / nl, "bytes_per_launch": bytes_total / nl,
                          "kernel_rays_per_s": (acc["closest"] + acc["shadow"]) / (acc["closest_ms"] * 1e-3)})
+            traffic, src = committed_traffic(args)
+            roof["traffic"] = traffic
+            roof["traffic_source"] = src
             out["config"]["gpu_over_cpu"] = value / base["value"]
         else:
             out["cpu_baseline"] = None

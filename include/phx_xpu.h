@@ -155,7 +155,11 @@ typedef struct phx_frame {
   /* optional: accumulate straight into a full-frame device-resident film (W*H*xstride fp32 in HBM,
    * e.g. a torch tensor's data_ptr) — used for the multi-GPU film reduce. */
   float*           device_film;
-  uint32_t         reserved[4];
+  /* optional: a full-frame HOST film (W*H*xstride fp32) the device fills tile by tile itself — the same
+   * effect as an add_tile callback that copies into a frame buffer (film::file_t, src/film/file.cpp:27-41)
+   * without a foreign-function call per tile. */
+  float*           host_film;
+  uint32_t         reserved[2];
 } phx_frame;
 
 /* ---- statistics ------------------------------------------------------------------------ */

@@ -79,7 +79,7 @@ class Frame(C.Structure):
     _fields_ = [
         ("tiles_user", C.c_void_p), ("next_tile", C.c_void_p), ("film_user", C.c_void_p), ("add_tile", C.c_void_p),
         ("sampler_seed", C.c_uint64), ("primary_components", C.c_uint32), ("normals_channel", C.c_uint32),
-        ("device_film", C.c_void_p), ("reserved", C.c_uint32 * 4),
+        ("device_film", C.c_void_p), ("host_film", C.c_void_p), ("reserved", C.c_uint32 * 2),
     ]
 
 

@@ -325,7 +325,7 @@ int phx_dev_start(phx_device* d, const phx_frame* f) {
   if (!d->preprocessed) return fail(PHX_ERR_STATE, "start before preprocess");
   if (d->running) return fail(PHX_ERR_STATE, "start while a frame is running");
   if (!f->next_tile) return fail(PHX_ERR_ARG, "frame without a tile queue");
-  if (!f->add_tile && !f->device_film) return fail(PHX_ERR_ARG, "frame without a film sink");
+  if (!f->add_tile && !f->device_film && !f->host_film) return fail(PHX_ERR_ARG, "frame without a film sink");
   if (f->primary_components != 3 && f->primary_components != 4) return fail(PHX_ERR_ARG, "primary channel must have 3 or 4 components");
   d->frame = *f;
   d->running = true;
@@ -593,7 +593,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     launch_scatter_film(stream, B, frame.device_film, scene.width);
     HIPCHK(hipGetLastError());
   }
-  if (frame.add_tile) {
+  if (frame.add_tile || frame.host_film) {
     const size_t nfl = (size_t)P * xs;
     if (nfl > h_acc_n) {
       if (h_acc) (void)hipHostFree(h_acc);
@@ -604,7 +604,10 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     HIPCHK(hipStreamSynchronize(stream));
     size_t off = 0;
     for (auto& t : tiles) {
-      frame.add_tile(frame.film_user, (int32_t)t.x, (int32_t)t.y, (int32_t)t.w, (int32_t)t.h, h_acc + off, xs, xs * t.w);
+      if (frame.add_tile) frame.add_tile(frame.film_user, (int32_t)t.x, (int32_t)t.y, (int32_t)t.w, (int32_t)t.h, h_acc + off, xs, xs * t.w);
+      if (frame.host_film)
+        for (uint32_t y = 0; y < t.h; ++y)
+          std::memcpy(frame.host_film + ((size_t)(t.y + y) * scene.width + t.x) * xs, h_acc + off + (size_t)y * t.w * xs, (size_t)t.w * xs * sizeof(float));
       off += (size_t)t.w * t.h * xs;
     }
   } else {

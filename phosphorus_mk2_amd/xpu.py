@@ -153,8 +153,9 @@ class Film:
 class FrameState:
     """frame_state_t (src/state.hpp:18-31).  `sampler_seed` replaces the shared sampler_t."""
 
-    def __init__(self, sampler_seed, tiles, film, device_film_ptr=None):
+    def __init__(self, sampler_seed, tiles, film, device_film_ptr=None, native_sink=False):
         self.sampler_seed, self.tiles, self.film, self.device_film_ptr = sampler_seed, tiles, film, device_film_ptr
+        self.native_sink = native_sink  # fill film.data from C (phx_frame.host_film) instead of one Python add_tile call per tile
 
 
 class HipDevice:
@@ -213,8 +214,11 @@ class HipDevice:
 
             def _add(user, x, y, w, h, buf, xs, ys):
                 film.add_tile(x, y, w, h, buf, xs, ys)
-            cb_add = abi.ADD_TILE_FN(_add)
-            f.add_tile = C.cast(cb_add, C.c_void_p)
+            if frame.native_sink:
+                f.host_film = film.data.ctypes.data
+            else:
+                cb_add = abi.ADD_TILE_FN(_add)
+                f.add_tile = C.cast(cb_add, C.c_void_p)
             f.primary_components = film.primary_components
             f.normals_channel = 1 if film.normals else 0
         else:
@@ -275,7 +279,7 @@ class HipDevice:
 
 
 def render(scene_desc, spp=16, pps=1, depth=9, seed=1, normals=False, tile_size=32, rank=0, world=1, callback_tiles=False,
-           samples_in_flight=0, tiles_per_batch=0):
+           samples_in_flight=0, tiles_per_batch=0, native_sink=False):
     """Convenience: the call sequence of session_t::render (plugins/blender/session.cpp:73-94):
     discover -> preprocess -> tiles_t::make -> start -> join.  Returns (film array HxWxC, stats)."""
     opts = Options(samples_per_pixel=spp, paths_per_sample=pps, path_depth=depth, samples_in_flight=samples_in_flight,
@@ -294,7 +298,7 @@ def render(scene_desc, spp=16, pps=1, depth=9, seed=1, normals=False, tile_size=
                 lst.append(t)
             tiles = CallbackTiles(lst)
         film = Film(W, H, 4, normals)
-        dev.start(scene_desc, FrameState(seed, tiles, film))
+        dev.start(scene_desc, FrameState(seed, tiles, film, native_sink=native_sink))
         dev.join()
         return film.data, dev.stats()
     finally:

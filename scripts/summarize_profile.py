@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (scripts/profile_gpu.sh) into the committed summaries under profiles/:
+  profiles/<name>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of one full bench frame
+  profiles/<name>_pmc.json           per-kernel PMC sums + HBM traffic per launch of the dominant kernel
+HBM traffic follows MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB, collected in separate passes;
+on gfx950 FETCH_SIZE counts half the bytes of wide streaming reads, so the corrected figure doubles it (this
+kernel's reads are 16-B-per-lane gathers, an access shape the guide calls uncalibrated: both raw and corrected
+values are recorded)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+
+
+def kname(s):
+    return s.split("(")[0].replace("void phx::", "").replace("phx::", "")
+
+
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = kname(r["Kernel_Name"])
+        if k.startswith("k_"):
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[k].add((os.path.dirname(f), r["Dispatch_Id"]))
+out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 18",
+       "kernels": {}}
+for k, a in agg.items():
+    n = len({d for (_, d) in launches[k]})
+    e = {"launches": n, "counters": dict(a)}
+    if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+        raw = (a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0
+        cor = (2.0 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0
+        e["hbm_bytes_per_launch_raw"] = raw / n
+        e["hbm_bytes_per_launch_corrected"] = cor / n
+    if "TCC_HIT" in a:
+        e["l2_hit_rate"] = a["TCC_HIT"] / (a["TCC_HIT"] + a["TCC_MISS"])
+    if "SQ_THREAD_CYCLES_VALU" in a and "SQ_INSTS_VALU" in a:
+        e["valu_lane_utilisation"] = a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_INSTS_VALU"] * 64.0)
+    out["kernels"][k] = e
+json.dump(out, open(os.path.join(dst, f"{name}_pmc.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: {x: v for x, v in e.items() if x != "counters"} for k, e in out["kernels"].items()}, indent=1))

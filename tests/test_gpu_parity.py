@@ -150,7 +150,8 @@ def test_invariances(xpu):
     a, _ = xpu.render(sc, spp=9, seed=4, samples_in_flight=1)
     b, _ = xpu.render(sc, spp=9, seed=4, samples_in_flight=4, tiles_per_batch=5)
     c, _ = xpu.render(sc, spp=9, seed=4, callback_tiles=True)
-    assert bits_equal(base, a) and bits_equal(base, b) and bits_equal(base, c)
+    d, _ = xpu.render(sc, spp=9, seed=4, native_sink=True)  # phx_frame.host_film instead of add_tile callbacks
+    assert bits_equal(base, a) and bits_equal(base, b) and bits_equal(base, c) and bits_equal(base, d)
     r0, _ = xpu.render(sc, spp=9, seed=4, rank=0, world=2)
     r1, _ = xpu.render(sc, spp=9, seed=4, rank=1, world=2)
     assert bits_equal(r0 + r1, base)  # disjoint tiles: the film reduce is exact
