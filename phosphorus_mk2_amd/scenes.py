@@ -207,6 +207,52 @@ def soup(n, seed=1234, width=1280, height=720, fov=1.9, light=True, materials=No
     return SceneDesc(meshes, mats, CameraDesc(width, height, fov), name=f"soup{n}")
 
 
+def smooth_blobs(width=96, height=64, per_vertex=True):
+    """Smooth-shaded geometry for the interpolated-normal path of mesh_t::shading_parameters
+    (src/mesh.cpp:187-199): two subdivided octahedra ("blobs") with per-vertex normals — or per-face-corner
+    normals when `per_vertex` is False (set_normals_per_vertex_per_face, src/mesh.hpp:64) — inside a
+    flat-shaded floor/back wall, lit by TWO emissive quads (light pick by index, src/sampling.cpp:165) of
+    which one is a 4-triangle strip (uniform triangle pick, src/light.cpp:55)."""
+    def octa(centre, radius, levels):
+        v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+        f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+        v = [np.array(x, np.float64) for x in v]
+        for _ in range(levels):
+            nf, cache = [], {}
+            def mid(a, b):
+                k = (min(a, b), max(a, b))
+                if k not in cache:
+                    m = v[a] + v[b]; v.append(m / np.linalg.norm(m)); cache[k] = len(v) - 1
+                return cache[k]
+            for a, b, c in f:
+                ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+                nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+            f = nf
+        n = np.array(v, np.float32)
+        return (n * np.float32(radius) + np.array(centre, np.float32)).astype(np.float32), n, np.array(f, np.uint32)
+    mats = [diffuse(0.73, 0.73, 0.73), diffuse(0.2, 0.5, 0.7),
+            MaterialDesc([LobeDesc(abi.LOBE_DIFFUSE, (0.5, 0.4, 0.3)), LobeDesc(abi.LOBE_MICROFACET, (0.3, 0.3, 0.3), xalpha=0.09, yalpha=0.09)]),
+            emitter(*LE), emitter(4.0, 4.0, 6.0)]
+    meshes = [
+        _quad((-2, -1, -1), (2, -1, -1), (2, -1, -4), (-2, -1, -4), 0),
+        _quad((-2, -1, -4), (2, -1, -4), (2, 2, -4), (-2, 2, -4), 0),
+    ]
+    for centre, radius, mat in (((-0.6, -0.4, -2.6), 0.6, 1), ((0.7, -0.5, -2.2), 0.5, 2)):
+        v, n, f = octa(centre, radius, 2)
+        if per_vertex:
+            m = MeshDesc(vertices=v, faces=f, normals=n, smooth=np.ones(len(f), np.uint8), sets=[(mat, np.arange(len(f), dtype=np.uint32))])
+        else:  # one normal per face corner, indexed by 3*face + corner (mesh.cpp:188-192); every other face flat
+            smooth = (np.arange(len(f)) % 2 == 0).astype(np.uint8)
+            m = MeshDesc(vertices=v, faces=f, normals=n[f.reshape(-1)], smooth=smooth, sets=[(mat, np.arange(len(f), dtype=np.uint32))],
+                         flags=abi.MESH_UV_PER_VERTEX)
+        meshes.append(m)
+    meshes.append(_quad((-0.5, 1.9, -2.0), (-0.5, 1.9, -3.0), (0.5, 1.9, -3.0), (0.5, 1.9, -2.0), 3))
+    strip_v = np.array([(-1.9, 0.0, -1.2), (-1.9, 1.0, -1.2), (-1.9, 0.0, -2.0), (-1.9, 1.0, -2.0), (-1.9, 0.0, -2.8), (-1.9, 1.0, -2.8)], np.float32)
+    strip_f = np.array([(0, 2, 1), (1, 2, 3), (2, 4, 3), (3, 4, 5)], np.uint32)  # normals +x
+    meshes.append(MeshDesc(vertices=strip_v, faces=strip_f, sets=[(4, np.arange(4, dtype=np.uint32))]))
+    return SceneDesc(meshes, mats, CameraDesc(width, height, 1.6), name="smooth_blobs")
+
+
 def closure_zoo():
     """One material per lobe type of src/bsdf.hpp:14-24 plus mixes, mirroring the constant-input
     mappings of the BSDF-node shaders: used by the BSDF known-answer tests and

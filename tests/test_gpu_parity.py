@@ -129,6 +129,19 @@ def test_render_all_closures_matches_oracle(xpu, orc):
     assert bits_equal(film[..., :3][fin], ref[..., :3][fin])
 
 
+@pytest.mark.parametrize("per_vertex", [True, False])
+def test_smooth_normals_and_several_lights(xpu, orc, per_vertex):
+    """interpolated normals (per vertex / per face corner, mesh.cpp:187-199), two area lights of 2 and 4
+    triangles (light + triangle pick by index), a two-lobe material: the general (non diffuse-only) k_shade."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.smooth_blobs(per_vertex=per_vertex)
+    film, st, (ref, ost, nref) = _render_both(xpu, orc, sc, spp=9, seed=13, normals=True)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+    assert max_pixel_l2(film, ref) < L2_TOL
+    assert bits_equal(film[..., :3], ref[..., :3]) and bits_equal(film[..., 4:7], nref)
+    assert np.abs(np.linalg.norm(nref, axis=-1)[nref.any(axis=-1)] - 1).max() < 1e-5
+
+
 def test_normals_channel_and_env_light(xpu, orc):
     from phosphorus_mk2_amd import scenes
     sc = scenes.cornell(64, 64)

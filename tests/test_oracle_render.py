@@ -59,6 +59,22 @@ def test_paths_per_sample_only_scales(orc):
     assert np.allclose(a / 4, b, rtol=1e-6)
 
 
+def test_smooth_scene_sanity(orc):
+    """interpolated normals are unit length, both lights contribute, sequential and counter modes agree"""
+    from phosphorus_mk2_amd import scenes
+    for pv in (True, False):
+        sc = scenes.smooth_blobs(48, 32, per_vertex=pv)
+        O = orc.Oracle(sc, spp=16)
+        a, sa, n = O.render(rng=orc.RNG_COUNTER, seed=2, threads=8, normals=True)
+        ln = np.linalg.norm(n, axis=-1)
+        assert np.isfinite(a).all() and np.abs(ln[ln > 0] - 1).max() < 1e-5
+        b, sb = O.render(rng=orc.RNG_SEQ)
+        assert abs(np.clip(a[..., :3], 0, 4).mean() / np.clip(b[..., :3], 0, 4).mean() - 1) < 0.1
+    pick = np.linspace(0.01, 0.99, 50).astype(np.float32)
+    p, uv, pdf, mesh, face = O.light_sample(pick, np.full((50, 2), 0.5, np.float32))
+    assert set(np.unique(mesh & 0xffff)) == {4, 5}  # both emissive meshes get picked
+
+
 def test_regression_film(orc):
     """tests/golden/oracle_cornell_32x32_spp4.npy: written by tests/golden/make_oracle_pins.py from THIS
     oracle (a regression pin, not a reference-derived vector)."""
