@@ -534,7 +534,15 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   for (auto& t : tiles) P += t.w * t.h;
   const uint32_t spp = opt.samples_per_pixel;
   uint32_t S = opt.samples_in_flight;
-  if (S == 0) { const uint64_t budget = 16u << 20; S = (uint32_t)std::max<uint64_t>(1, budget / P); }
+  if (S == 0) {
+    // paths in flight: ~128 M (about 20 GB of queues + state: sized for 288 GB of HBM).  Deep bounces keep only
+    // a few percent of the paths alive, so many samples per pass are what keeps late launches full; the spp
+    // range is then split into equal passes.
+    const uint64_t budget = 128ull << 20;
+    const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / P, 0x7ffffff0ull / P));
+    const uint32_t npasses = (spp + smax - 1) / smax;
+    S = (spp + npasses - 1) / npasses;
+  }
   S = std::min(S, spp);
   const size_t npaths = (size_t)P * S;
   if (npaths >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");

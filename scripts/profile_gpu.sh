@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box (gpurun -- 'bash scripts/profile_gpu.sh <tag>'): rocprofv3 kernel-trace stats of one full
 # bench frame + the PMC passes (each in its own run, per MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE cannot
-# share a pass) on a one-pass frame (18 spp = one wavefront pass of BASELINE's 1280x720 workload).
+# share a pass) on one full frame of the same command.
 # Outputs land under gpurun_out/prof_<tag>/; scripts/summarize_profile.py turns them into profiles/*.json.
 TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/stats.log 2>&1
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 18 > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$name.log 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU

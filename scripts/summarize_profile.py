@@ -35,7 +35,7 @@ for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[k].add((os.path.dirname(f), r["Dispatch_Id"]))
-out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 18",
+out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
        "kernels": {}}
 for k, a in agg.items():
     n = len({d for (_, d) in launches[k]})
