@@ -100,6 +100,12 @@ PHX_HD uint32_t perm_xor8(uint32_t x, uint32_t oct) {
 }
 
 // The 8 box tests of one node for one ray: bit i of the result = child slot i may be hit.
+// Conservative: entry distance scaled by (1 - 2^-21), exit distance by (1 + 2^-21) (4 ulp each; tn >= 0, and a
+// negative exit distance is a miss either way), IEEE maxNum/minNum.  On the device the near/far planes of an
+// axis go through one packed FMA (v_pk_fma_f32) and the two pads through one packed multiply.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float phx_f2 __attribute__((ext_vector_type(2)));
+#endif
 PHX_HD uint32_t node_hit8(const uint32_t* w /* 20 words of the node */, const RayCtx& r, float tmax) {
   const float px = u32_as_f32(w[0]), py = u32_as_f32(w[1]), pz = u32_as_f32(w[2]);
   const uint32_t e = w[3];
@@ -107,8 +113,12 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 20 words of the node */, const Ra
   const float ax = sx * r.idx, ay = sy * r.idy, az = sz * r.idz;
   const float bx = (px - r.o.x) * r.idx, by = (py - r.o.y) * r.idy, bz = (pz - r.o.z) * r.idz;
   const bool nx = r.idx < 0.0f, ny = r.idy < 0.0f, nz = r.idz < 0.0f;
+  const float pad_near = 0.999999523162841796875f, pad_far = 1.000000476837158203125f;  // 1 -/+ 2^-21
   // words: 8,9 qlox | 10,11 qloy | 12,13 qloz | 14,15 qhix | 16,17 qhiy | 18,19 qhiz
   uint32_t hit8 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const phx_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz}, pad2 = {pad_near, pad_far};
+#endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const uint32_t nearx = nx ? w[14 + half] : w[8 + half], farx = nx ? w[8 + half] : w[14 + half];
@@ -117,17 +127,27 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 20 words of the node */, const Ra
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sh = 8 * j;
+#if defined(__HIP_DEVICE_COMPILE__)
+      const phx_f2 qx = {(float)((nearx >> sh) & 0xffu), (float)((farx >> sh) & 0xffu)};
+      const phx_f2 qy = {(float)((neary >> sh) & 0xffu), (float)((fary >> sh) & 0xffu)};
+      const phx_f2 qz = {(float)((nearz >> sh) & 0xffu), (float)((farz >> sh) & 0xffu)};
+      const phx_f2 tx = __builtin_elementwise_fma(qx, ax2, bx2);
+      const phx_f2 ty = __builtin_elementwise_fma(qy, ay2, by2);
+      const phx_f2 tz = __builtin_elementwise_fma(qz, az2, bz2);
+      phx_f2 t = {fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f)), fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax))};
+      t = t * pad2;
+      if (t.x <= t.y) hit8 |= 1u << (4 * half + j);  // empty slots have inverted boxes (qlo 255 > qhi 0)
+#else
       const float tnx = fmaf((float)((nearx >> sh) & 0xffu), ax, bx);
       const float tny = fmaf((float)((neary >> sh) & 0xffu), ay, by);
       const float tnz = fmaf((float)((nearz >> sh) & 0xffu), az, bz);
       const float tfx = fmaf((float)((farx >> sh) & 0xffu), ax, bx);
       const float tfy = fmaf((float)((fary >> sh) & 0xffu), ay, by);
       const float tfz = fmaf((float)((farz >> sh) & 0xffu), az, bz);
-      float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-      float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
-      tn = tn - fabsf(tn) * 4.76837158203125e-7f;  // pad both ends by 4 ulp: never reject a box that holds a hit
-      tf = tf + fabsf(tf) * 4.76837158203125e-7f;
-      if (tn <= tf) hit8 |= 1u << (4 * half + j);  // empty slots have inverted boxes (qlo 255 > qhi 0)
+      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f)) * pad_near;
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)) * pad_far;
+      if (tn <= tf) hit8 |= 1u << (4 * half + j);
+#endif
     }
   }
   return hit8;

@@ -95,6 +95,7 @@ struct LdsStack {
 // One stream serves BOTH queues: lanes are refilled from the workgroup's shadow-ray range first, then from
 // its closest-hit range; the any-hit / closest-hit distinction is a per-lane flag, so a launch has a single
 // drain phase (the tail where rays run out and lanes idle) instead of one per queue.
+#define PHX_STEPS_PER_REFILL 1
 template <int BLOCK>
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
                                              uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t refill_min,
@@ -134,6 +135,8 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       if (phase < 2u && __ballot(active) == 0ull) continue;  // nothing in flight yet: go fetch from the next range
     }
     if (!__ballot(active)) break;
+#pragma unroll
+    for (int step = 0; step < PHX_STEPS_PER_REFILL; ++step)
     if (active) {
       // ---- one node visit
       if (th == 0 && ng_hits > 0x00ffffffu) {
@@ -287,8 +290,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) k_shade(DevScene sc, PassBuff
     path = pbits & 0x7fffffffu;
     const bool specular = (pbits >> 31) != 0;
     const float4 bd = pb.pb[path];
-    float4 rr = pb.pr[path];
-    v3 beta(bd.x, bd.y, bd.z), rad(rr.x, rr.y, rr.z);
+    v3 beta(bd.x, bd.y, bd.z);
+    // radiance is only read-modified-written when this step adds something: out += beta * e with e == 0 and a
+    // finite beta leaves `out` unchanged bit for bit (out is never -0), so the 32 B of traffic are skipped
+    v3 add_e(0.0f); bool add_rad = false;
+    const bool beta_finite = isfinite(bd.x) && isfinite(bd.y) && isfinite(bd.z);
     uint32_t depth = f2u(bd.w);
     const uint32_t s = path / pb.num_pixels, pix = path - s * pb.num_pixels;
     const uint32_t xy = pb.pix_xy[pix];
@@ -304,7 +310,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) k_shade(DevScene sc, PassBuff
       const v3 n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
       if (pb.pn && depth == 0) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
       const v3 e(m.ex, m.ey, m.ez);
-      if (depth == 0 || specular) rad = rad + beta * e;  // spt.hpp:177-179
+      if (depth == 0 || specular) { add_e = e; add_rad = true; }  // spt.hpp:177-179
       // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
       {
         const uint32_t b0 = depth * DIMS_PER_STEP;
@@ -375,11 +381,15 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) k_shade(DevScene sc, PassBuff
       // miss: environment lighting (deferred_shading_kernel.hpp:65-70, spt.hpp:199-202)
       v3 e(0.0f);
       if (sc.env_material >= 0) { const DevMaterial& m = sc.materials[sc.env_material]; e = v3(m.ex, m.ey, m.ez); }
-      rad = rad + beta * e;
+      add_e = e; add_rad = true;
       masked = true;  // a miss still occupies a (MASKED|SHADOW) slot in the reference's shadow stream (spt.hpp:138-141)
     }
     pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));
-    pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+    if (add_rad && !(beta_finite && add_e.x == 0.0f && add_e.y == 0.0f && add_e.z == 0.0f)) {
+      const float4 rr = pb.pr[path];
+      const v3 rad = v3(rr.x, rr.y, rr.z) + v3(bd.x, bd.y, bd.z) * add_e;  // beta as it was when the ray arrived
+      pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+    }
   }
   // ---- stream compaction: survivors -> next ray queue, unmasked NEE rays -> shadow queue
   const uint32_t no = block_append(alive, &pb.counters[q ^ 1], lds_cnt, 0);
