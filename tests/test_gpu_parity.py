@@ -173,6 +173,43 @@ def test_invariances(xpu):
     assert not bits_equal(base, other)
 
 
+def test_hybrid_cpu_gpu_share_one_tile_queue(xpu, orc):
+    """The reference's hybrid mechanism: several xpu_t devices drain ONE job::tiles_t (src/core.cpp:103-108).
+    Here the gfx950 device and a CPU worker (the oracle, standing in for cpu_t) pull from the same queue;
+    whoever renders a tile, the film is the same bit for bit."""
+    import threading
+    from phosphorus_mk2_amd import dist, scenes
+    sc = scenes.cornell(160, 128)
+    all_tiles = dist.shard_tiles(160, 128, 32, 0, 1)
+    queue = xpu.CallbackTiles(all_tiles)
+    film = xpu.Film(160, 128, 4)
+    O = orc.Oracle(sc, spp=4)
+    cpu_tiles = []
+
+    def cpu_device():
+        while True:
+            t = queue.next()
+            if t is None:
+                return
+            part, _ = O.render(rng=orc.RNG_COUNTER, seed=6, threads=1, tiles=[t])
+            x, y, w, h = t
+            with film._lock:
+                film.data[y:y + h, x:x + w, :] = part[y:y + h, x:x + w, :]
+            cpu_tiles.append(t)
+
+    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, tiles_per_batch=2))[0]
+    dev.preprocess(sc)
+    worker = threading.Thread(target=cpu_device)
+    dev.start(sc, xpu.FrameState(6, queue, film))
+    worker.start()
+    dev.join(); worker.join()
+    gpu_tiles = dev.stats()["tiles"]
+    assert gpu_tiles + len(cpu_tiles) == len(all_tiles) and gpu_tiles > 0
+    ref, _ = O.render(rng=orc.RNG_COUNTER, seed=6, threads=4)
+    assert bits_equal(film.data[..., :3], ref[..., :3])
+    dev.close()
+
+
 def test_error_behaviour(xpu):
     from phosphorus_mk2_amd import scenes
     dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1))
