@@ -274,11 +274,32 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
 }
 
 template <bool DIFFUSE_ONLY>
-__global__ void __launch_bounds__(PHX_SHADE_BLOCK) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+__global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q];
-  const uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
+  uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
   if (blockIdx.x * PHX_SHADE_BLOCK >= count) return;
+  if (!DIFFUSE_ONLY) {
+    // Bucket the workgroup's 512 hits by material before shading them — what deferred_shading_kernel_t does per
+    // 1024-slot stream (deferred_t::material, deferred_shading_kernel.hpp:9-33, 63) — so that a wave evaluates a few
+    // closure recipes instead of up to 64 different ones.  Counting sort through LDS on (material mod 32).
+    __shared__ uint32_t bucket[33];
+    __shared__ uint16_t perm[PHX_SHADE_BLOCK];
+    if (threadIdx.x < 33) bucket[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t key = 32u;  // misses and out-of-range slots go last
+    if (i < count) {
+      const uint32_t tri = f2u(pb.hit[i].w);
+      if (tri != 0xffffffffu) key = sc.tris[tri].material & 31u;
+    }
+    const uint32_t rank = atomicAdd(&bucket[key], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int k = 0; k < 33; ++k) { const uint32_t c = bucket[k]; bucket[k] = acc; acc += c; } }
+    __syncthreads();
+    perm[bucket[key] + rank] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    i = blockIdx.x * PHX_SHADE_BLOCK + perm[threadIdx.x];
+  }
   const bool live = i < count;
   bool alive = false, want_shadow = false, masked = false;
   uint32_t path = 0, next_specular = 0;
