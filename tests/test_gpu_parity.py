@@ -173,6 +173,18 @@ def test_invariances(xpu):
     assert not bits_equal(base, other)
 
 
+def test_loaded_yaml_obj_scene_matches_oracle(xpu, orc):
+    """scene ingestion -> preprocess -> render: baked shader graphs (glossy GGX, emitter, background), OBJ mesh with
+    per-face-corner normals, look-at camera, environment material"""
+    import os
+    from conftest import ROOT
+    from phosphorus_mk2_amd import sceneio
+    sc = sceneio.load_scene(os.path.join(ROOT, "tests", "golden", "room", "scene.yaml"))
+    film, st, (ref, ost) = _render_both(xpu, orc, sc, spp=16, seed=5)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+    assert bits_equal(film[..., :3], ref[..., :3]) and film[..., :3].max() > 0.1
+
+
 def test_hybrid_cpu_gpu_share_one_tile_queue(xpu, orc):
     """The reference's hybrid mechanism: several xpu_t devices drain ONE job::tiles_t (src/core.cpp:103-108).
     Here the gfx950 device and a CPU worker (the oracle, standing in for cpu_t) pull from the same queue;
