@@ -483,8 +483,8 @@ void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& 
 }
 void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
                   int camera_rays) {
-  static const int gmul = getenv("PHX_TRACE_GRID") ? atoi(getenv("PHX_TRACE_GRID")) : 2;
-  static const int gmul0 = getenv("PHX_TRACE_GRID0") ? atoi(getenv("PHX_TRACE_GRID0")) : 8;
+  static const int gmul = getenv("PHX_TRACE_GRID") ? atoi(getenv("PHX_TRACE_GRID")) : 4;
+  static const int gmul0 = getenv("PHX_TRACE_GRID0") ? atoi(getenv("PHX_TRACE_GRID0")) : 16;
   static const int inter0 = getenv("PHX_TRACE_INTER0") ? atoi(getenv("PHX_TRACE_INTER0")) : 1;
   static const uint32_t refill = getenv("PHX_REFILL") ? (uint32_t)atoi(getenv("PHX_REFILL")) : 8u;
   static const uint32_t block = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 256u;
