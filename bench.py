@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-tiles", type=int, default=100000, help="tiles of the frame in the CPU baseline sample")
     p.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel in the CPU baseline sample")
+    p.add_argument("--bvh-builder", choices=["host", "device"], default="host", help="host binned SAH (default) or device LBVH")
     p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
     return p.parse_args()
 
@@ -114,7 +115,8 @@ def main():
 
     scene = scenes.soup(args.triangles, seed=1234, width=args.width, height=args.height)
     opts = xpu.Options(samples_per_pixel=args.spp, paths_per_sample=1, path_depth=args.depth,
-                       device_ordinal=local_rank if use_dist else -1, samples_in_flight=args.samples_in_flight)
+                       device_ordinal=local_rank if use_dist else -1, samples_in_flight=args.samples_in_flight,
+                       bvh_builder=args.bvh_builder)
     dev = xpu.HipDevice.discover(opts)[0]
     t0 = time.time()
     dev.preprocess(scene)  # flatten + BVH build + upload: outside the timed region
@@ -178,7 +180,8 @@ def main():
                                    "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
                        "tiles": "32x32, tile i -> rank i % n_gpus", "film_collective": "reduce(sum) to rank 0" if use_dist else "none",
                        "rays_per_step": rays_total / args.steps, "camera_samples_per_step": W * H * args.spp,
-                       "preprocess_s": preprocess_s, "bvh_bytes": st["bvh_bytes"], "film_mean": float(film[..., :3].mean()),
+                       "preprocess_s": preprocess_s, "bvh_builder": args.bvh_builder, "bvh_build_ms": st["bvh_build_ms"],
+                       "bvh_bytes": st["bvh_bytes"], "film_mean": float(film[..., :3].mean()),
                        "film_finite": bool(np.isfinite(film).all())},
         }
         roof = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}

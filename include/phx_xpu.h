@@ -61,8 +61,10 @@ typedef struct phx_options {
   int32_t  device_ordinal;    /* HIP device index; -1 = current device */
   uint32_t samples_in_flight; /* samples of one pixel carried per wavefront pass */
   uint32_t tiles_per_batch;   /* tiles pulled from the queue per pass */
-  uint32_t reserved[6];
+  uint32_t bvh_builder;       /* PHX_BVH_HOST_SAH (default) or PHX_BVH_DEVICE_LBVH: where preprocess builds the tree */
+  uint32_t reserved[5];
 } phx_options;
+enum { PHX_BVH_HOST_SAH = 0, PHX_BVH_DEVICE_LBVH = 1 };
 
 /* ---- scene: what the device reads through scene_t (src/scene.hpp:14-50) --------------- */
 
@@ -178,7 +180,9 @@ typedef struct phx_stats {
   uint64_t bvh_nodes;
   uint64_t bvh_bytes;
   uint64_t triangles;
-  uint64_t reserved[8];
+  double   preprocess_ms;    /* wall time of the last phx_dev_preprocess */
+  double   bvh_build_ms;     /* of which: tree construction (host SAH, or device LBVH incl. its upload of the triangles) */
+  uint64_t reserved[6];
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

@@ -11,6 +11,7 @@ LOBE_EMISSIVE, LOBE_DIFFUSE, LOBE_OREN_NAYAR, LOBE_REFLECTION = 0, 1, 2, 4
 LOBE_REFRACTION, LOBE_MICROFACET, LOBE_SHEEN, LOBE_BACKGROUND, LOBE_TRANSPARENT = 8, 16, 32, 64, 128
 BSDF_DIFFUSE, BSDF_GLOSSY, BSDF_SPECULAR, BSDF_REFLECT, BSDF_TRANSMIT = 1, 2, 4, 8, 16
 MAX_LOBES = 8
+BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
 MESH_UV_PER_VERTEX, MESH_NORMALS_PER_VERTEX = 1, 2
 
 f32p = C.POINTER(C.c_float)
@@ -23,7 +24,7 @@ class Options(C.Structure):
         ("samples_per_pixel", C.c_uint32), ("paths_per_sample", C.c_uint32), ("path_depth", C.c_uint32),
         ("single_threaded", C.c_uint32), ("host_only", C.c_uint32), ("render_normals", C.c_uint32),
         ("verbose", C.c_uint32), ("device_ordinal", C.c_int32), ("samples_in_flight", C.c_uint32),
-        ("tiles_per_batch", C.c_uint32), ("reserved", C.c_uint32 * 6),
+        ("tiles_per_batch", C.c_uint32), ("bvh_builder", C.c_uint32), ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -89,7 +90,7 @@ class Stats(C.Structure):
         ("rays_masked", C.c_uint64), ("tiles", C.c_uint64), ("trace_launches", C.c_uint64),
         ("trace_ms", C.c_double), ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
         ("frame_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64), ("triangles", C.c_uint64),
-        ("reserved", C.c_uint64 * 8),
+        ("preprocess_ms", C.c_double), ("bvh_build_ms", C.c_double), ("reserved", C.c_uint64 * 6),
     ]
 
 

@@ -57,7 +57,11 @@ PHX_HD int popc32(uint32_t x) {
 PHX_HD float u32_as_f32(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 
 // Reference Moeller-Trumbore (src/accel/triangle.hpp:149-164) for one ray and one triangle.
-PHX_HD bool mt_intersect(const TriRec& T, const v3& o, const v3& wi, float tmax, float& us, float& vs, float& ds) {
+// `best_prim`: primitive of the hit that set tmax (0 while the ray has none).  Two triangles can be hit at bitwise the same
+// distance (they intersect each other); the reference then keeps whichever its traversal order meets first (strict d < tmax),
+// which makes its result depend on the tree.  Here the tie goes to the lowest primitive index, so the closest hit is a function
+// of the ray and the triangle set alone — whichever builder made the tree.
+PHX_HD bool mt_intersect(const TriRec& T, const v3& o, const v3& wi, float tmax, uint32_t best_prim, float& us, float& vs, float& ds) {
   const v3 e0(T.e0x, T.e0y, T.e0z), e1(T.e1x, T.e1y, T.e1z), v0(T.v0x, T.v0y, T.v0z);
   const v3 t = o - v0;
   const v3 p = scross(wi, e1);
@@ -70,7 +74,7 @@ PHX_HD bool mt_intersect(const TriRec& T, const v3& o, const v3& wi, float tmax,
   const bool xmask = (det > 0.00000001f) || (det < -0.00000001f);
   const bool umask = us >= 0.0f;
   const bool vmask = (vs >= 0.0f) && ((us + vs) <= 1.0f);
-  const bool dmask = (ds >= 0.0f) && (ds < tmax);
+  const bool dmask = (ds >= 0.0f) && ((ds < tmax) || (ds == tmax && T.prim < best_prim));
   return vmask && umask && dmask && xmask;
 }
 
@@ -170,6 +174,7 @@ PHX_HD bool traverse8(const uint32_t* __restrict__ nodes /* 20 words per node */
                       uint32_t* node_visits = nullptr, uint32_t* tri_tests = nullptr) {
   const RayCtx r = make_ray_ctx(o, d);
   hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xffffffffu;
+  uint32_t best_prim = 0;
   uint32_t ng_base = 0, ng_hits = 0x80000000u;  // the root as a one-child group
   for (;;) {
     // visit the nearest not-yet-visited inner child of the current group
@@ -203,8 +208,8 @@ PHX_HD bool traverse8(const uint32_t* __restrict__ nodes /* 20 words per node */
       const TriRec T = tris[ti];
       float us, vs, ds;
       if (tri_tests) ++*tri_tests;
-      if (mt_intersect(T, o, d, hit.t, us, vs, ds)) {
-        hit.t = ds; hit.u = us; hit.v = vs; hit.tri = ti;
+      if (mt_intersect(T, o, d, hit.t, best_prim, us, vs, ds)) {
+        hit.t = ds; hit.u = us; hit.v = vs; hit.tri = ti; best_prim = T.prim;
         if (ANY) return true;
       }
     }

@@ -1,0 +1,23 @@
+// bvh_gpu.h — device-side LBVH build of the BVH8 of bvh8.h (see bvh_gpu.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "bvh8.h"
+
+namespace phx {
+
+struct GpuBvh {
+  Node8* nodes;   // hipMalloc'd, owned by the caller after a successful build
+  TriRec* tris;   // hipMalloc'd, material word already filled
+  uint32_t num_nodes, num_tris, depth;
+};
+
+// d_abc: 9 floats per primitive (a, b, c) in scene_t::triangles() order, device memory.
+// d_prim_material: per-primitive material word (material | smooth << 31), device memory.
+// Returns 0 on success; on failure writes a message to err and leaves *out empty.
+int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen);
+
+}  // namespace phx

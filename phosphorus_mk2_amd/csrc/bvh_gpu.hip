@@ -1,0 +1,333 @@
+// bvh_gpu.hip — device-side construction of the BVH8 of bvh8.h (replace the host
+// recursion of the reference builder, src/accel/bvh/binned_sah_builder.hpp:216-281, by a GPU build so that
+// preprocess() can rebuild per frame like cpu_t::preprocess does, src/xpu/cpu.cpp:35-44,219).
+//
+// LBVH pipeline, everything resident in HBM:
+//   k_prim_bounds   triangle boxes + centroid bounds of the scene (wave shuffle reduce, ordered-uint atomics)
+//   k_morton        63-bit Morton code of the centroid (21 bits per axis) + primitive index
+//   rocprim::radix_sort_pairs                      (library radix sort of 8-byte keys: not a hot-path kernel)
+//   k_radix_tree    Karras 2012: one thread per internal node of the binary radix tree over the sorted codes
+//   k_fit           bottom-up boxes + leaf counts (second arrival at a node continues upwards)
+//   k_collapse      per BVH8 node, level by level: greedy surface-area expansion to <= 8 children (subtrees of
+//                   <= 3 triangles become leaf slots), octant-order slot assignment, outward quantisation,
+//                   triangle records in tmask bit order — the same node semantics as the host builder.
+// Traversal results do not depend on which builder made the tree (conservative box tests, bvh8.h).
+#include "bvh_gpu.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace phx {
+namespace {
+
+#define GB 256
+
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ inline float ord2f(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  union { uint32_t u; float f; } c; c.u = u; return c.f;
+}
+
+struct Box6 { float lo[3], hi[3]; };
+
+__global__ void __launch_bounds__(GB) k_prim_bounds(const float* __restrict__ abc, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ cb /* 6 ordered uints */) {
+  const uint32_t i = blockIdx.x * GB + threadIdx.x;
+  float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < n) {
+    const float* t = abc + 9 * (size_t)i;
+    Box6 b;
+    for (int a = 0; a < 3; ++a) {
+      b.lo[a] = fminf(fminf(t[a], t[3 + a]), t[6 + a]);
+      b.hi[a] = fmaxf(fmaxf(t[a], t[3 + a]), t[6 + a]);
+      clo[a] = chi[a] = 0.5f * (b.lo[a] + b.hi[a]);
+    }
+    pbox[i] = b;
+  }
+  for (int a = 0; a < 3; ++a) {
+    float lo = clo[a], hi = chi[a];
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (__lane_id() == 0) { atomicMin(&cb[a], f2ord(lo)); atomicMax(&cb[3 + a], f2ord(hi)); }
+  }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t x) {  // 21 bits -> every third bit of 63
+  uint64_t v = x & 0x1fffffu;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ void __launch_bounds__(GB) k_morton(const Box6* __restrict__ pbox, uint32_t n, const uint32_t* __restrict__ cb, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * GB + threadIdx.x;
+  if (i >= n) return;
+  uint32_t q[3];
+  for (int a = 0; a < 3; ++a) {
+    const float lo = ord2f(cb[a]), hi = ord2f(cb[3 + a]);
+    const float c = 0.5f * (pbox[i].lo[a] + pbox[i].hi[a]);
+    const float ext = hi - lo;
+    float u = ext > 0.0f ? (c - lo) / ext : 0.0f;
+    u = fminf(fmaxf(u, 0.0f), 1.0f);
+    q[a] = (uint32_t)fminf(u * 2097152.0f, 2097151.0f);
+  }
+  keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  vals[i] = i;
+}
+
+// common-prefix length of sorted keys i and j (ties broken by the index), -1 outside the array
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((unsigned)(i ^ j));
+  return __clzll((long long)(a ^ b));
+}
+
+// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (2012), section 3.
+// Internal nodes 0..n-2, leaves are encoded as (n-1+k).  Requires n >= 2.
+__global__ void __launch_bounds__(GB) k_radix_tree(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                                   uint32_t* __restrict__ parent, uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
+  const int i = blockIdx.x * GB + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + s * d + (d < 0 ? -1 : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const uint32_t lc = (lo == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+  const uint32_t rc = (hi == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+  left[i] = lc; right[i] = rc;
+  parent[lc] = (uint32_t)i; parent[rc] = (uint32_t)i;
+  first[i] = (uint32_t)lo; last[i] = (uint32_t)hi;
+  if (i == 0) parent[0] = 0xffffffffu;
+}
+
+// boxes of all 2n-1 nodes; node ids as above.  flags[] must be zero.
+__global__ void __launch_bounds__(GB) k_fit(const Box6* __restrict__ pbox, const uint32_t* __restrict__ sorted, int n, const uint32_t* __restrict__ left,
+                                            const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* __restrict__ flags,
+                                            Box6* __restrict__ nbox) {
+  const int k = blockIdx.x * GB + threadIdx.x;
+  if (k >= n) return;
+  uint32_t node = (uint32_t)(n - 1 + k);
+  nbox[node] = pbox[sorted[k]];
+  __threadfence();
+  uint32_t p = parent[node];
+  while (p != 0xffffffffu) {
+    if (atomicAdd(&flags[p], 1u) == 0u) return;  // first arrival: the sibling subtree is not finished yet
+    __threadfence();
+    const Box6 a = nbox[left[p]], b = nbox[right[p]];
+    Box6 m;
+    for (int x = 0; x < 3; ++x) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+    nbox[p] = m;
+    __threadfence();
+    p = parent[p];
+  }
+}
+
+struct Tree2 {
+  const uint32_t* left; const uint32_t* right; const uint32_t* first; const uint32_t* last; const Box6* nbox; const uint32_t* sorted;
+  int n;
+};
+
+__device__ __forceinline__ float area6(const Box6& b) {
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+__device__ __forceinline__ uint32_t leaf_count(const Tree2& T, uint32_t node) {
+  return node >= (uint32_t)(T.n - 1) ? 1u : T.last[node] - T.first[node] + 1u;
+}
+__device__ __forceinline__ uint32_t first_prim(const Tree2& T, uint32_t node) {
+  return node >= (uint32_t)(T.n - 1) ? node - (uint32_t)(T.n - 1) : T.first[node];
+}
+
+#define LEAF_SLOT_MAX 3u
+
+// One thread builds one Node8 from BVH2 subtree `qa[e]` into node slot `qb[e]`.
+__global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restrict__ abc, const uint32_t* __restrict__ prim_material, const uint32_t* __restrict__ qa,
+                                                 const uint32_t* __restrict__ qb, uint32_t count, uint32_t* __restrict__ qa_out, uint32_t* __restrict__ qb_out,
+                                                 uint32_t* __restrict__ counters /* [0] nodes, [1] tris, [2] out queue */, Node8* __restrict__ nodes,
+                                                 TriRec* __restrict__ tris) {
+  const uint32_t e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= count) return;
+  const uint32_t root2 = qa[e], n8 = qb[e];
+  uint32_t ch[8]; int nch = 0;
+  if (leaf_count(T, root2) <= LEAF_SLOT_MAX) { ch[nch++] = root2; }  // degenerate: the whole tree is one leaf slot
+  else {
+    ch[nch++] = T.left[root2]; ch[nch++] = T.right[root2];
+    while (nch < 8) {
+      int pick = -1; float best = -1.0f;
+      for (int i = 0; i < nch; ++i) {
+        if (leaf_count(T, ch[i]) <= LEAF_SLOT_MAX) continue;
+        const float a = area6(T.nbox[ch[i]]);
+        if (a > best) { best = a; pick = i; }
+      }
+      if (pick < 0) break;
+      const uint32_t c = ch[pick];
+      ch[pick] = T.left[c]; ch[nch++] = T.right[c];
+    }
+  }
+  const Box6 nb = T.nbox[root2];
+  // octant-order slots: greedy minimum of dot(child centre - node centre, slot direction)
+  int slot_of[8]; bool used[8] = {false, false, false, false, false, false, false, false}, done[8] = {false, false, false, false, false, false, false, false};
+  float cen[8][3];
+  for (int i = 0; i < nch; ++i) { const Box6 b = T.nbox[ch[i]]; for (int a = 0; a < 3; ++a) cen[i][a] = 0.5f * (b.lo[a] + b.hi[a]) - 0.5f * (nb.lo[a] + nb.hi[a]); }
+  for (int k = 0; k < nch; ++k) {
+    int bi = -1, bs = -1; float bc = FLT_MAX;
+    for (int i = 0; i < nch; ++i) if (!done[i])
+      for (int s = 0; s < 8; ++s) if (!used[s]) {
+        const float v = cen[i][0] * ((s & 4) ? -1.0f : 1.0f) + cen[i][1] * ((s & 2) ? -1.0f : 1.0f) + cen[i][2] * ((s & 1) ? -1.0f : 1.0f);
+        if (v < bc) { bc = v; bi = i; bs = s; }
+      }
+    slot_of[bi] = bs; used[bs] = true; done[bi] = true;
+  }
+  int child_in_slot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  for (int i = 0; i < nch; ++i) child_in_slot[slot_of[i]] = i;
+
+  Node8 nd;
+  nd.px = nb.lo[0]; nd.py = nb.lo[1]; nd.pz = nb.lo[2];
+  nd.imask = 0; nd.tmask = 0; nd.pad = 0;
+  double scale[3]; uint8_t eb[3];
+  for (int a = 0; a < 3; ++a) {
+    const double ext = (double)(nb.hi[a] - nb.lo[a]);
+    int ex = -126;
+    if (ext > 0.0) {
+      ex = (int)ceil(log2(ext * 1.00001 / 255.0));
+      while (ldexp(255.0, ex) < ext * 1.00001) ++ex;
+    }
+    ex = max(-126, min(127, ex));
+    eb[a] = (uint8_t)(ex + 127);
+    scale[a] = ldexp(1.0, ex);
+  }
+  nd.ex = eb[0]; nd.ey = eb[1]; nd.ez = eb[2];
+  uint32_t n_inner = 0, n_tri = 0;
+  for (int s = 0; s < 8; ++s) {
+    const int i = child_in_slot[s];
+    uint8_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
+    if (i >= 0) {
+      const Box6 b = T.nbox[ch[i]];
+      for (int a = 0; a < 3; ++a) {
+        double lo = floor(((double)b.lo[a] - (double)nb.lo[a]) / scale[a] - 1e-3);
+        double hi = ceil(((double)b.hi[a] - (double)nb.lo[a]) / scale[a] + 1e-3);
+        lo = fmax(0.0, fmin(255.0, lo)); hi = fmax(0.0, fmin(255.0, hi));
+        ql[a] = (uint8_t)lo; qh[a] = (uint8_t)hi;
+      }
+      const uint32_t cnt = leaf_count(T, ch[i]);
+      if (cnt <= LEAF_SLOT_MAX) { for (uint32_t k = 0; k < cnt; ++k) nd.tmask |= 1u << (s + 8 * (int)k); n_tri += cnt; }
+      else { nd.imask |= (uint8_t)(1u << s); ++n_inner; }
+    }
+    nd.qlox[s] = ql[0]; nd.qloy[s] = ql[1]; nd.qloz[s] = ql[2]; nd.qhix[s] = qh[0]; nd.qhiy[s] = qh[1]; nd.qhiz[s] = qh[2];
+  }
+  nd.child_base = n_inner ? atomicAdd(&counters[0], n_inner) : 0u;
+  nd.tri_base = n_tri ? atomicAdd(&counters[1], n_tri) : 0u;
+  // triangle records in tmask bit order: bit (s + 8*j) = j-th triangle of leaf slot s
+  uint32_t w = 0;
+  for (int bit = 0; bit < 24; ++bit) {
+    if (!(nd.tmask & (1u << bit))) continue;
+    const int s = bit & 7, k = bit >> 3;
+    const uint32_t p = T.sorted[first_prim(T, ch[child_in_slot[s]]) + (uint32_t)k];
+    const float* t = abc + 9 * (size_t)p;
+    TriRec R;
+    R.v0x = t[0]; R.v0y = t[1]; R.v0z = t[2];
+    R.e0x = t[3] - t[0]; R.e0y = t[4] - t[1]; R.e0z = t[5] - t[2];  // e0 = b - a, e1 = c - a (accel/triangle.hpp:48-50)
+    R.e1x = t[6] - t[0]; R.e1y = t[7] - t[1]; R.e1z = t[8] - t[2];
+    R.prim = p; R.material = prim_material[p]; R.pad1 = 0;
+    tris[nd.tri_base + w++] = R;
+  }
+  nodes[n8] = nd;
+  if (n_inner) {
+    const uint32_t qpos = atomicAdd(&counters[2], n_inner);
+    uint32_t r = 0;
+    for (int s = 0; s < 8; ++s)
+      if (nd.imask & (1u << s)) { qa_out[qpos + r] = ch[child_in_slot[s]]; qb_out[qpos + r] = nd.child_base + r; ++r; }
+  }
+}
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::snprintf(err, errlen, "%s: %s", #x, hipGetErrorString(e_)); cleanup(); return 1; } } while (0)
+
+}  // namespace
+
+int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen) {
+  out->nodes = nullptr; out->tris = nullptr; out->num_nodes = 0; out->num_tris = 0; out->depth = 1;
+  void* bufs[16]; int nb = 0;
+  auto cleanup = [&]() { for (int i = 0; i < nb; ++i) (void)hipFree(bufs[i]); };
+  auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; bufs[nb++] = p; return p; };
+  if (n < 2) { std::snprintf(err, errlen, "device builder needs at least 2 triangles"); return 1; }
+  Box6* pbox = (Box6*)dalloc(sizeof(Box6) * n);
+  uint32_t* cb = (uint32_t*)dalloc(64);
+  uint64_t* keys = (uint64_t*)dalloc(8 * (size_t)n); uint64_t* keys2 = (uint64_t*)dalloc(8 * (size_t)n);
+  uint32_t* vals = (uint32_t*)dalloc(4 * (size_t)n); uint32_t* sorted = (uint32_t*)dalloc(4 * (size_t)n);
+  uint32_t* left = (uint32_t*)dalloc(4 * (size_t)n); uint32_t* right = (uint32_t*)dalloc(4 * (size_t)n);
+  uint32_t* parent = (uint32_t*)dalloc(4 * 2 * (size_t)n); uint32_t* first = (uint32_t*)dalloc(4 * (size_t)n); uint32_t* last = (uint32_t*)dalloc(4 * (size_t)n);
+  uint32_t* flags = (uint32_t*)dalloc(4 * (size_t)n);
+  Box6* nbox = (Box6*)dalloc(sizeof(Box6) * 2 * (size_t)n);
+  uint32_t* queues = (uint32_t*)dalloc(4 * 4 * (size_t)n);
+  uint32_t* counters = (uint32_t*)dalloc(64);
+  if (!pbox || !cb || !keys || !keys2 || !vals || !sorted || !left || !right || !parent || !first || !last || !flags || !nbox || !queues || !counters) {
+    std::snprintf(err, errlen, "hipMalloc failed in the device BVH builder"); cleanup(); return 1;
+  }
+  const uint32_t init_cb[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  HCHK(hipMemcpyAsync(cb, init_cb, sizeof(init_cb), hipMemcpyHostToDevice, stream));
+  const dim3 g((n + GB - 1) / GB), b(GB);
+  hipLaunchKernelGGL(k_prim_bounds, g, b, 0, stream, d_abc, n, pbox, cb);
+  hipLaunchKernelGGL(k_morton, g, b, 0, stream, pbox, n, cb, keys, vals);
+  size_t temp_bytes = 0;
+  HCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
+  void* temp = dalloc(temp_bytes);
+  if (!temp) { std::snprintf(err, errlen, "hipMalloc failed (sort scratch)"); cleanup(); return 1; }
+  HCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
+  hipLaunchKernelGGL(k_radix_tree, g, b, 0, stream, keys2, (int)n, left, right, parent, first, last);
+  HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));
+  hipLaunchKernelGGL(k_fit, g, b, 0, stream, pbox, sorted, (int)n, left, right, parent, flags, nbox);
+  HCHK(hipGetLastError());
+
+  // outputs: at most n-1 inner BVH2 nodes can become Node8s (+1), exactly n triangle records
+  Node8* nodes = nullptr; TriRec* tris = nullptr;
+  if (hipMalloc((void**)&nodes, sizeof(Node8) * (size_t)n) != hipSuccess || hipMalloc((void**)&tris, sizeof(TriRec) * (size_t)n) != hipSuccess) {
+    if (nodes) (void)hipFree(nodes);
+    std::snprintf(err, errlen, "hipMalloc failed (BVH8 arrays)"); cleanup(); return 1;
+  }
+  uint32_t* qa[2] = {queues, queues + 2 * (size_t)n}; uint32_t* qb[2] = {queues + (size_t)n, queues + 3 * (size_t)n};
+  const uint32_t zero_root[2] = {0u, 0u};
+  HCHK(hipMemcpyAsync(qa[0], &zero_root[0], 4, hipMemcpyHostToDevice, stream));
+  HCHK(hipMemcpyAsync(qb[0], &zero_root[1], 4, hipMemcpyHostToDevice, stream));
+  uint32_t h_counters[3] = {1u, 0u, 0u};  // node 0 is the root
+  HCHK(hipMemcpyAsync(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
+  Tree2 T{left, right, first, last, nbox, sorted, (int)n};
+  uint32_t count = 1, depth = 0; int cur = 0;
+  while (count > 0) {
+    ++depth;
+    hipLaunchKernelGGL(k_collapse, dim3((count + 63) / 64), dim3(64), 0, stream, T, d_abc, d_prim_material, qa[cur], qb[cur], count, qa[cur ^ 1], qb[cur ^ 1],
+                       counters, nodes, tris);
+    HCHK(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+    HCHK(hipStreamSynchronize(stream));
+    count = h_counters[2];
+    const uint32_t z = 0;
+    HCHK(hipMemcpyAsync(counters + 2, &z, 4, hipMemcpyHostToDevice, stream));
+    cur ^= 1;
+    if (depth > 64) break;
+  }
+  HCHK(hipStreamSynchronize(stream));
+  out->nodes = nodes; out->tris = tris; out->num_nodes = h_counters[0]; out->num_tris = h_counters[1]; out->depth = depth;
+  cleanup();
+  if (out->num_tris != n) { std::snprintf(err, errlen, "device BVH builder lost triangles (%u of %u)", out->num_tris, n); (void)hipFree(nodes); (void)hipFree(tris); out->nodes = nullptr; out->tris = nullptr; return 1; }
+  return 0;
+}
+
+}  // namespace phx

@@ -7,6 +7,7 @@
 // There is no CPU rendering path in this library: without a gfx950 device every entry point fails.
 #include "../../include/phx_xpu.h"
 #include "bvh_build.h"
+#include "bvh_gpu.h"
 #include "kernels.h"
 
 #include <atomic>
@@ -49,6 +50,7 @@ struct DevBuf {
     if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return PHX_OK;
   }
+  void adopt(T* ptr, size_t count) { release(); p = ptr; n = count; }  // take ownership of a hipMalloc'd array
   void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
   ~DevBuf() { release(); }
 };
@@ -72,6 +74,7 @@ struct phx_device {
   DevScene scene{};
   uint32_t num_materials = 0;
   uint64_t bvh_nodes = 0, bvh_bytes = 0, num_triangles = 0;
+  double preprocess_ms = 0, bvh_build_ms = 0;
 
   // pass buffers
   DevBuf<float4> ro[2], rd[2], hit, so, sd, sc, pb, pr, pn;
@@ -215,6 +218,7 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
     return fail(PHX_ERR_ARG, "film size out of range");
   if (s->environment_material >= (int32_t)s->num_materials) return fail(PHX_ERR_ARG, "environment material out of range");
   HIPCHK(hipSetDevice(d->hip_device));
+  const auto t_pre0 = std::chrono::steady_clock::now();
 
   // triangles in scene_t::triangles() order: mesh order x face-set order (scene.cpp:58-62, mesh.cpp:118-128)
   std::vector<float> abc; std::vector<uint32_t> prim_material; std::vector<float> prim_normals;
@@ -275,16 +279,31 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
   for (uint32_t i = 0; i < s->num_materials; ++i)
     if (bake_material(s->materials[i], L5, mats[i])) return fail(PHX_ERR_ARG, "material with an unknown closure id");
 
-  Bvh8 bvh;
-  const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
-  build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads);
-
-  for (auto& T : bvh.tris) T.material = prim_material[T.prim];
-
   int rc;
-  if ((rc = d->d_nodes.upload(bvh.nodes))) return rc;
-  if ((rc = d->d_tris.upload(bvh.tris))) return rc;
   if ((rc = d->d_prim_material.upload(prim_material))) return rc;
+  const auto t_bvh0 = std::chrono::steady_clock::now();
+  uint32_t bvh_depth = 0; size_t bvh_node_count = 0;
+  if (d->opt.bvh_builder == PHX_BVH_DEVICE_LBVH) {
+    // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
+    DevBuf<float> d_abc;
+    if ((rc = d_abc.upload(abc))) return rc;
+    GpuBvh g{}; char msg[256] = {0};
+    if (build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, (uint32_t)prim_material.size(), &g, msg, sizeof(msg)))
+      return fail(PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
+    d->d_nodes.adopt(g.nodes, g.num_nodes); d->d_tris.adopt(g.tris, g.num_tris);
+    bvh_depth = g.depth; bvh_node_count = g.num_nodes;
+  } else if (d->opt.bvh_builder == PHX_BVH_HOST_SAH) {
+    Bvh8 bvh;
+    const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads);
+    for (auto& T : bvh.tris) T.material = prim_material[T.prim];
+    if ((rc = d->d_nodes.upload(bvh.nodes))) return rc;
+    if ((rc = d->d_tris.upload(bvh.tris))) return rc;
+    bvh_depth = bvh.depth; bvh_node_count = bvh.nodes.size();
+  } else {
+    return fail(PHX_ERR_ARG, "unknown bvh_builder");
+  }
+  const auto t_bvh1 = std::chrono::steady_clock::now();
   if ((rc = d->d_prim_normals.upload(prim_normals))) return rc;
   if ((rc = d->d_materials.upload(mats))) return rc;
   if ((rc = d->d_lights.upload(lights))) return rc;
@@ -304,8 +323,8 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
   sc.ratio = (float)s->camera.film_width / (float)s->camera.film_height;
   sc.width = s->camera.film_width; sc.height = s->camera.film_height;
   sc.max_depth = d->opt.path_depth;
-  sc.stack_levels = bvh.depth;
-  sc.num_nodes = (uint32_t)bvh.nodes.size();
+  sc.stack_levels = bvh_depth;
+  sc.num_nodes = (uint32_t)bvh_node_count;
   {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, d->hip_device));
     sc.num_cus = (uint32_t)prop.multiProcessorCount;
@@ -313,8 +332,10 @@ int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
   sc.diffuse_only = 1;
   for (auto& m : mats) for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0;
   d->num_materials = s->num_materials;
-  d->bvh_nodes = bvh.nodes.size();
-  d->bvh_bytes = bvh.nodes.size() * sizeof(Node8) + bvh.tris.size() * sizeof(TriRec);
+  d->bvh_nodes = bvh_node_count;
+  d->bvh_bytes = bvh_node_count * sizeof(Node8) + prim_material.size() * sizeof(TriRec);
+  d->bvh_build_ms = std::chrono::duration<double, std::milli>(t_bvh1 - t_bvh0).count();
+  d->preprocess_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pre0).count();
   d->num_triangles = prim_material.size();
   d->preprocessed = true;
   return PHX_OK;
@@ -347,6 +368,7 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   if (!d || !out) return fail(PHX_ERR_ARG, "get_stats: null argument");
   *out = d->stats;
   out->bvh_nodes = d->bvh_nodes; out->bvh_bytes = d->bvh_bytes; out->triangles = d->num_triangles;
+  out->preprocess_ms = d->preprocess_ms; out->bvh_build_ms = d->bvh_build_ms;
   return PHX_OK;
 }
 

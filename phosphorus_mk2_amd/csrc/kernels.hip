@@ -106,7 +106,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   uint32_t phase = 0;  // wave-uniform: 0 = shadow range, 1 = closest range, 2 = drained
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
   float tbest = 0.f, hu = 0.f, hv = 0.f;
-  uint32_t htri = 0xffffffffu, idx = 0, ng_base = 0, ng_hits = 0, tb = 0, th = 0, tm = 0, path = 0;
+  uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, tb = 0, th = 0, tm = 0, path = 0;
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
@@ -125,7 +125,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           float4 a, b;
           if (phase == 0u) { a = pb.so[my]; b = pb.sd[my]; } else { a = ro[my]; b = rd[my]; }
           r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
-          tbest = b.w; hu = 0.f; hv = 0.f; htri = 0xffffffffu; idx = my; path = f2u(a.w);
+          tbest = b.w; hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my; path = f2u(a.w);
           ng_base = 0; ng_hits = 0x80000000u; tb = 0; th = 0; sp = 0;
           any = phase == 0u;
           active = true;
@@ -168,8 +168,8 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         const uint32_t ti = tb + (uint32_t)__popc(tm & ~(0xffffffffu << k));
         const TriRec T = sc.tris[ti];
         float us, vs, ds;
-        if (mt_intersect(T, r.o, r.d, tbest, us, vs, ds)) {
-          tbest = ds; hu = us; hv = vs; htri = ti;
+        if (mt_intersect(T, r.o, r.d, tbest, hprim, us, vs, ds)) {
+          tbest = ds; hu = us; hv = vs; htri = ti; hprim = T.prim;
           if (any) active = false;  // occluded: nothing to add
         }
       }

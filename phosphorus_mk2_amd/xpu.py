@@ -53,7 +53,7 @@ class Options:
     """parsed_options_t (src/options.hpp:6-43) plus the device knobs."""
 
     def __init__(self, samples_per_pixel=16, paths_per_sample=16, path_depth=9, single_threaded=False, host_only=False,
-                 render_normals=False, verbose=False, device_ordinal=-1, samples_in_flight=0, tiles_per_batch=0):
+                 render_normals=False, verbose=False, device_ordinal=-1, samples_in_flight=0, tiles_per_batch=0, bvh_builder="host"):
         self.samples_per_pixel = samples_per_pixel
         self.paths_per_sample = paths_per_sample
         self.path_depth = path_depth
@@ -64,6 +64,7 @@ class Options:
         self.device_ordinal = device_ordinal
         self.samples_in_flight = samples_in_flight
         self.tiles_per_batch = tiles_per_batch
+        self.bvh_builder = bvh_builder  # "host": binned SAH on the host cores; "device": LBVH built on the GPU
 
     def pack(self):
         o = abi.Options()
@@ -71,6 +72,7 @@ class Options:
         o.single_threaded, o.host_only = int(self.single_threaded), int(self.host_only)
         o.render_normals, o.verbose = int(self.render_normals), int(self.verbose)
         o.device_ordinal, o.samples_in_flight, o.tiles_per_batch = self.device_ordinal, self.samples_in_flight, self.tiles_per_batch
+        o.bvh_builder = {"host": abi.BVH_HOST_SAH, "device": abi.BVH_DEVICE_LBVH}[self.bvh_builder]
         return o
 
 
@@ -279,11 +281,11 @@ class HipDevice:
 
 
 def render(scene_desc, spp=16, pps=1, depth=9, seed=1, normals=False, tile_size=32, rank=0, world=1, callback_tiles=False,
-           samples_in_flight=0, tiles_per_batch=0, native_sink=False):
+           samples_in_flight=0, tiles_per_batch=0, native_sink=False, bvh_builder="host"):
     """Convenience: the call sequence of session_t::render (plugins/blender/session.cpp:73-94):
     discover -> preprocess -> tiles_t::make -> start -> join.  Returns (film array HxWxC, stats)."""
     opts = Options(samples_per_pixel=spp, paths_per_sample=pps, path_depth=depth, samples_in_flight=samples_in_flight,
-                   tiles_per_batch=tiles_per_batch)
+                   tiles_per_batch=tiles_per_batch, bvh_builder=bvh_builder)
     dev = HipDevice.discover(opts)[0]
     try:
         dev.preprocess(scene_desc)

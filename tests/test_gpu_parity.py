@@ -173,6 +173,35 @@ def test_invariances(xpu):
     assert not bits_equal(base, other)
 
 
+@pytest.mark.parametrize("name,n", [("cornell", 0), ("soup", 17), ("soup", 100000), ("blobs", 0)])
+def test_device_built_bvh_matches_host_built(xpu, orc, name, n):
+    """phx_options.bvh_builder = PHX_BVH_DEVICE_LBVH: the tree is built on the GPU (bvh_gpu.hip).  The box
+    tests are conservative, so hits, ray counts and the film must not depend on which builder made the tree."""
+    from phosphorus_mk2_amd import scenes
+    sc = {"cornell": lambda: scenes.cornell(64, 64), "soup": lambda: scenes.soup(n, width=64, height=64),
+          "blobs": lambda: scenes.smooth_blobs(64, 64)}[name]()
+    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder="device"))[0]
+    dev.preprocess(sc)
+    O = orc.Oracle(sc, spp=1)
+    o, d, tm = random_rays(40000, 23)
+    g = dev.trace(o, d, tm)
+    r = O.trace(o, d, tm)
+    assert np.array_equal(g["prim"], r["prim"])
+    assert bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    tm2 = np.full(len(tm), 0.7, np.float32)
+    assert np.array_equal(dev.trace(o, d, tm2, shadow=True)["hit"], O.trace(o, d, tm2, shadow=True)["hit"])
+    st = dev.stats()
+    assert st["bvh_nodes"] > 0 and st["triangles"] == O.bvh_info()["triangles"] and st["bvh_build_ms"] > 0
+    dev.close()
+    host, hst = xpu.render(sc, spp=8, seed=6)
+    devb, dst = xpu.render(sc, spp=8, seed=6, bvh_builder="device")
+    assert bits_equal(host, devb)
+    for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked"):
+        assert hst[k] == dst[k]
+    ref, _ = orc.Oracle(sc, spp=8, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=6, threads=8)
+    assert max_pixel_l2(devb, ref) < L2_TOL and bits_equal(devb[..., :3], ref[..., :3])
+
+
 def test_loaded_yaml_obj_scene_matches_oracle(xpu, orc):
     """scene ingestion -> preprocess -> render: baked shader graphs (glossy GGX, emitter, background), OBJ mesh with
     per-face-corner normals, look-at camera, environment material"""
