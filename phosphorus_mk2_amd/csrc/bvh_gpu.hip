@@ -9,7 +9,7 @@
 //   k_radix_tree    Karras 2012: one thread per internal node of the binary radix tree over the sorted codes
 //   k_fit           bottom-up boxes + leaf counts (second arrival at a node continues upwards)
 //   k_collapse      per BVH8 node, level by level: greedy surface-area expansion to <= 8 children (subtrees of
-//                   <= 3 triangles become leaf slots), octant-order slot assignment, outward quantisation,
+//                   <= leaf_max triangles become leaf slots), octant-order slot assignment, outward quantisation,
 //                   triangle records in tmask bit order — the same node semantics as the host builder.
 // Traversal results do not depend on which builder made the tree (conservative box tests, bvh8.h).
 #include "bvh_gpu.h"
@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -157,13 +158,12 @@ __device__ __forceinline__ uint32_t first_prim(const Tree2& T, uint32_t node) {
   return node >= (uint32_t)(T.n - 1) ? node - (uint32_t)(T.n - 1) : T.first[node];
 }
 
-#define LEAF_SLOT_MAX 3u
 
 // One thread builds one Node8 from BVH2 subtree `qa[e]` into node slot `qb[e]`.
 __global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restrict__ abc, const uint32_t* __restrict__ prim_material, const uint32_t* __restrict__ qa,
                                                  const uint32_t* __restrict__ qb, uint32_t count, uint32_t* __restrict__ qa_out, uint32_t* __restrict__ qb_out,
                                                  uint32_t* __restrict__ counters /* [0] nodes, [1] tris, [2] out queue */, Node8* __restrict__ nodes,
-                                                 TriRec* __restrict__ tris) {
+                                                 TriRec* __restrict__ tris, uint32_t LEAF_SLOT_MAX) {
   const uint32_t e = blockIdx.x * 64 + threadIdx.x;
   if (e >= count) return;
   const uint32_t root2 = qa[e], n8 = qb[e];
@@ -310,11 +310,13 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   uint32_t h_counters[3] = {1u, 0u, 0u};  // node 0 is the root
   HCHK(hipMemcpyAsync(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
   Tree2 T{left, right, first, last, nbox, sorted, (int)n};
+  uint32_t leaf_max = 1;  // measured on Soup(100k): 1-triangle leaf slots trace 23% faster than 3 (profiles/README.md)
+  if (const char* e = getenv("PHX_LBVH_LEAF")) leaf_max = (uint32_t)std::max(1, std::min(3, atoi(e)));
   uint32_t count = 1, depth = 0; int cur = 0;
   while (count > 0) {
     ++depth;
     hipLaunchKernelGGL(k_collapse, dim3((count + 63) / 64), dim3(64), 0, stream, T, d_abc, d_prim_material, qa[cur], qb[cur], count, qa[cur ^ 1], qb[cur ^ 1],
-                       counters, nodes, tris);
+                       counters, nodes, tris, leaf_max);
     HCHK(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
     HCHK(hipStreamSynchronize(stream));
     count = h_counters[2];
