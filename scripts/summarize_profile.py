@@ -29,14 +29,19 @@ if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
-for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
+passes = collections.defaultdict(set)  # a counter collected in several passes is averaged over them
+mem = os.path.join(root, "gpurun_out", f"mem_{tag}")  # scripts/profile_mem.sh: TA / TCP / TD passes of the same command
+for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")) + glob.glob(os.path.join(mem, "*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = kname(r["Kernel_Name"])
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            passes[(k, r["Counter_Name"])].add(os.path.dirname(f))
             launches[k].add((os.path.dirname(f), r["Dispatch_Id"]))
 out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
        "kernels": {}}
+for (k, c), ps in passes.items():
+    agg[k][c] /= len(ps)
 for k, a in agg.items():
     n = len({d for (_, d) in launches[k]})
     e = {"launches": n, "counters": dict(a)}
@@ -49,6 +54,16 @@ for k, a in agg.items():
         e["l2_hit_rate"] = a["TCC_HIT"] / (a["TCC_HIT"] + a["TCC_MISS"])
     if "SQ_THREAD_CYCLES_VALU" in a and "SQ_INSTS_VALU" in a:
         e["valu_lane_utilisation"] = a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_INSTS_VALU"] * 64.0)
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in a and "GRBM_GUI_ACTIVE" in a:
+        # vector-L1 path: lane addresses per clock and CU (ceiling measured by scripts/micro/l1_gather.hip: ~1.7, whatever the
+        # width of the load), and the busy fractions of the address (TA) and data-return (TD) units
+        cu_cycles = a["GRBM_GUI_ACTIVE"] / 8.0 * 256.0  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        e["l1_lane_accesses_per_clk_per_cu"] = a["TCP_TOTAL_CACHE_ACCESSES_sum"] / cu_cycles
+        e["ta_busy_frac"] = a.get("TA_TA_BUSY_sum", 0.0) / cu_cycles
+        e["td_busy_frac"] = a.get("TD_TD_BUSY_sum", 0.0) / cu_cycles
+        e["l1_hit_rate"] = 1.0 - a.get("TCP_TCC_READ_REQ_sum", 0.0) / a["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        if "SQ_WAIT_INST_ANY" in a and "SQ_WAVE_CYCLES" in a:
+            e["wave_cycles_waiting_frac"] = a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"]
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(dst, f"{name}_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {x: v for x, v in e.items() if x != "counters"} for k, e in out["kernels"].items()}, indent=1))
