@@ -202,6 +202,43 @@ def test_device_built_bvh_matches_host_built(xpu, orc, name, n):
     assert max_pixel_l2(devb, ref) < L2_TOL and bits_equal(devb[..., :3], ref[..., :3])
 
 
+def _room_scene():
+    """the scene examples/render_room.c builds in C, through the Python mirror"""
+    from phosphorus_mk2_amd import abi, scenes
+    v = np.array([[-2, -1, -1], [2, -1, -1], [2, -1, -5], [-2, -1, -5], [-2, -1, -5], [2, -1, -5], [2, 2, -5], [-2, 2, -5],
+                  [-1, 1.5, -2], [-1, 1.5, -4], [1, 1.5, -4], [1, 1.5, -2], [-0.8, -0.9, -3.2], [0.9, -0.6, -3.6], [0.1, 0.7, -3.0],
+                  [-1.5, -0.2, -4.2], [-0.6, 0.9, -4.4], [-1.7, 1.1, -3.9]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11], [12, 13, 14], [15, 16, 17]], np.uint32)
+    mats = [scenes.MaterialDesc([scenes.LobeDesc(abi.LOBE_DIFFUSE, (0.73, 0.73, 0.73))]),
+            scenes.MaterialDesc([], emission=(17.0, 12.0, 4.0), is_emitter=True),
+            scenes.MaterialDesc([scenes.LobeDesc(abi.LOBE_DIFFUSE, (0.63, 0.065, 0.05))])]
+    mesh = scenes.MeshDesc(v, f, [(0, [0, 1, 2, 3]), (1, [4, 5]), (2, [6, 7])])
+    return scenes.SceneDesc([mesh], mats, scenes.CameraDesc(128, 96, fov=1.2))
+
+
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_plain_c_host_renders_the_same_film(xpu, orc, builder, tmp_path):
+    """examples/render_room.c drives the C ABI from C (no Python, no torch in that process); its film must equal the
+    film of the same scene rendered through the ctypes mirror, and the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "render_room")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True)
+    out = str(tmp_path / "room.f32")
+    r = subprocess.run([exe, out] + (["device-bvh"] if builder == "device" else []), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    c_film = np.fromfile(out, np.float32).reshape(96, 128, 4)
+    sc = _room_scene()
+    film, st = xpu.render(sc, spp=8, pps=1, depth=5, seed=7, native_sink=True, bvh_builder=builder)
+    assert bits_equal(c_film, film)
+    assert f"rays {st['rays_closest']}+{st['rays_shadow']}" in r.stdout
+    ref, _ = orc.Oracle(sc, spp=8, pps=1, depth=5).render(rng=orc.RNG_COUNTER, seed=7, threads=4)
+    assert max_pixel_l2(c_film, ref) < L2_TOL and bits_equal(c_film[..., :3], ref[..., :3])
+    assert c_film[..., :3].max() > 0.05
+
+
 def test_loaded_yaml_obj_scene_matches_oracle(xpu, orc):
     """scene ingestion -> preprocess -> render: baked shader graphs (glossy GGX, emitter, background), OBJ mesh with
     per-face-corner normals, look-at camera, environment material"""
