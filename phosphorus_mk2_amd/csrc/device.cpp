@@ -605,16 +605,16 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   for (uint32_t s0 = 0; s0 < spp; s0 += S) {
     const uint32_t ns = std::min(S, spp - s0);
     const uint32_t cap = P * ns;
-    if ((rc = timed_launch(2, [&]() { launch_generate(stream, scene, B, s0, ns); }))) return rc;
+    if ((rc = timed_launch(2, [&]() { launch_begin_pass(stream, B, ns); }))) return rc;
     int q = 0;
     for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
       // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
       const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
-      if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap, bounce == 0); }))) return rc;
-      if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0); }))) return rc;
+      if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap, bounce == 0, s0); }))) return rc;
+      if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
       q ^= 1;
     }
-    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap, 0); }))) return rc;
+    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap, 0, s0); }))) return rc;
     if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
     HIPCHK(hipGetLastError());
   }

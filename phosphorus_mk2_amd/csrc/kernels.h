@@ -64,12 +64,13 @@ struct PassBuffers {
 };
 
 // launches (all asynchronous on `stream`)
-void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples);
+// start of a pass: queue 0 stands for the num_pixels x num_samples camera rays, which are rebuilt on the fly (camera_ray)
+void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples);
 // one persistent launch: closest-hit rays of queue q (do_closest) + any-hit rays of shadow queue sq (do_shadow)
 void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
-                  int camera_rays);
+                  int camera_rays, uint32_t sample0);
 // shades queue q, appends survivors to queue q^1 and NEE rays to shadow queue sq
-void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0);
+void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays);
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);
 void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width);
 

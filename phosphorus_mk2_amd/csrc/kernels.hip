@@ -40,15 +40,11 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, u
   return cnt[nwaves] + cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// ---- generate -------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PHX_BLOCK) k_generate(DevScene sc, PassBuffers pb, uint32_t sample0, uint32_t num_samples) {
-  const uint32_t path = blockIdx.x * PHX_BLOCK + threadIdx.x;
-  const uint32_t npaths = pb.num_pixels * num_samples;
-  if (path == 0) {
-    pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + 1] = 0;
-    atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
-  }
-  if (path >= npaths) return;
+// ---- camera rays ------------------------------------------------------------------------------------
+// camera::perspective_kernel_t (kernels/cpu/camera.hpp:80-159), pinhole.  Primary rays are never stored: the first
+// k_trace of a pass and the first k_shade both rebuild the ray of path `path` from the pixel table and the jitter table
+// (about 40 instructions) instead of writing and re-reading 32 B per path.
+__device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers& pb, uint32_t path, uint32_t sample0, v3& p, v3& w) {
   const uint32_t s = path / pb.num_pixels, pix = path - s * pb.num_pixels;
   const uint32_t xy = pb.pix_xy[pix];
   const float sx = (float)(xy & 0xffffu), sy = (float)(xy >> 16);
@@ -61,18 +57,20 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_generate(DevScene sc, PassBuffers
   const float ool = 1.0f / sqrtf(sdot(d, d));
   d = v3(d.x * ool, d.y * ool, d.z * ool);
   const float* M = sc.cam_m;
-  v3 p, w;
   { float t = 0.0f * M[0]; t = fmaf(0.0f, M[4], t); t = fmaf(0.0f, M[8], t); p.x = t + M[12]; }
   { float t = 0.0f * M[1]; t = fmaf(0.0f, M[5], t); t = fmaf(0.0f, M[9], t); p.y = t + M[13]; }
   { float t = 0.0f * M[2]; t = fmaf(0.0f, M[6], t); t = fmaf(0.0f, M[10], t); p.z = t + M[14]; }
   { float t = d.x * M[0]; t = fmaf(d.y, M[4], t); w.x = fmaf(d.z, M[8], t); }
   { float t = d.x * M[1]; t = fmaf(d.y, M[5], t); w.y = fmaf(d.z, M[9], t); }
   { float t = d.x * M[2]; t = fmaf(d.y, M[6], t); w.z = fmaf(d.z, M[10], t); }
-  pb.ro[0][path] = make_float4(p.x, p.y, p.z, u2f(path));
-  pb.rd[0][path] = make_float4(w.x, w.y, w.z, FLT_MAX);
-  pb.pb[path] = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));
-  pb.pr[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (pb.pn) pb.pn[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// start of a pass: queue 0 "holds" the num_pixels x num_samples camera rays (state_t::reset, spt.hpp:39-49, is implicit:
+// the first k_shade writes beta, depth and radiance of every path without reading them)
+__global__ void k_begin_pass(PassBuffers pb, uint32_t num_samples) {
+  const uint32_t npaths = pb.num_pixels * num_samples;
+  pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + 1] = 0;
+  atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
 }
 
 // ---- trace ----------------------------------------------------------------------------------------
@@ -96,10 +94,10 @@ struct LdsStack {
 // its closest-hit range; the any-hit / closest-hit distinction is a per-lane flag, so a launch has a single
 // drain phase (the tail where rays run out and lanes idle) instead of one per queue.
 #define PHX_STEPS_PER_REFILL 1
-template <int BLOCK>
+template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */>
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
                                              uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t refill_min,
-                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop) {
+                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0) {
   const uint32_t lane = __lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   bool active = false, any = false;
@@ -122,10 +120,18 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       if (!active) {
         const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
         if (my < hi) {
-          float4 a, b;
-          if (phase == 0u) { a = pb.so[my]; b = pb.sd[my]; } else { a = ro[my]; b = rd[my]; }
-          r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
-          tbest = b.w; hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my; path = f2u(a.w);
+          if (GEN && phase == 1u) {
+            v3 co, cd;
+            camera_ray(sc, pb, my, sample0, co, cd);
+            r = make_ray_ctx(co, cd);
+            tbest = FLT_MAX; path = my;
+          } else {
+            float4 a, b;
+            if (phase == 0u) { a = pb.so[my]; b = pb.sd[my]; } else { a = ro[my]; b = rd[my]; }
+            r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+            tbest = b.w; path = f2u(a.w);
+          }
+          hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
           ng_base = 0; ng_hits = 0x80000000u; tb = 0; th = 0; sp = 0;
           any = phase == 0u;
           active = true;
@@ -201,9 +207,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 // workgroups and every workgroup owns one contiguous range of each queue.  The split is XCD-aware:
 // workgroups b, b+8, ... share an XCD and its L2, so each XCD gets a contiguous eighth of the queue.
 // Dynamic LDS layout: [ntop nodelets x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
-template <int BLOCK>
+template <int BLOCK, bool GEN>
 __global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
-                                                 int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks) {
+                                                 int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * 5u);
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, in
   for (uint32_t i = threadIdx.x; i < ntop * 5u; i += BLOCK) top[i] = g4[i];
   if (threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
   __syncthreads();
-  trace_stream<BLOCK>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop);
+  trace_stream<BLOCK, GEN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0);
 }
 
 template <int LEVELS, bool ANY>
@@ -273,7 +279,7 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
   return (float)0.212671 * c.x + (float)0.715160 * c.y + (float)0.072169 * c.z;
 }
 
-template <bool DIFFUSE_ONLY>
+template <bool DIFFUSE_ONLY, bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q];
@@ -306,11 +312,20 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
   v3 nxt_o, nxt_d, sh_o, sh_d, contrib;
   float sh_t = 0.0f;
   if (live) {
-    const float4 a = pb.ro[q][i], b = pb.rd[q][i], h = pb.hit[i];
+    float4 a, b, bd;
+    const float4 h = pb.hit[i];
+    if (FIRST) {
+      v3 co, cd;
+      camera_ray(sc, pb, i, sample0, co, cd);
+      a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
+      bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
+    } else {
+      a = pb.ro[q][i]; b = pb.rd[q][i];
+    }
     const uint32_t pbits = f2u(a.w);
     path = pbits & 0x7fffffffu;
     const bool specular = (pbits >> 31) != 0;
-    const float4 bd = pb.pb[path];
+    if (!FIRST) bd = pb.pb[path];
     v3 beta(bd.x, bd.y, bd.z);
     // radiance is only read-modified-written when this step adds something: out += beta * e with e == 0 and a
     // finite beta leaves `out` unchanged bit for bit (out is never -0), so the 32 B of traffic are skipped
@@ -329,7 +344,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
       const v3 p = o + d * h.x;            // hits.p = p + wi*d
       const v3 wo = -d;                    // hits.wi = -wi
       const v3 n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
-      if (pb.pn && depth == 0) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
+      if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
       const v3 e(m.ex, m.ey, m.ez);
       if (depth == 0 || specular) { add_e = e; add_rad = true; }  // spt.hpp:177-179
       // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
@@ -403,10 +418,14 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
       v3 e(0.0f);
       if (sc.env_material >= 0) { const DevMaterial& m = sc.materials[sc.env_material]; e = v3(m.ex, m.ey, m.ez); }
       add_e = e; add_rad = true;
+      if (FIRST && pb.pn) pb.pn[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       masked = true;  // a miss still occupies a (MASKED|SHADOW) slot in the reference's shadow stream (spt.hpp:138-141)
     }
     pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));
-    if (add_rad && !(beta_finite && add_e.x == 0.0f && add_e.y == 0.0f && add_e.z == 0.0f)) {
+    if (FIRST) {  // r = 0 + beta * e: every path's radiance is written here, nothing is read
+      const v3 rad = v3(0.0f) + v3(bd.x, bd.y, bd.z) * add_e;
+      pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+    } else if (add_rad && !(beta_finite && add_e.x == 0.0f && add_e.y == 0.0f && add_e.z == 0.0f)) {
       const float4 rr = pb.pr[path];
       const v3 rad = v3(rr.x, rr.y, rr.z) + v3(bd.x, bd.y, bd.z) * add_e;  // beta as it was when the ray arrived
       pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
@@ -477,12 +496,11 @@ __global__ void k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n
 
 // ---- launches ---------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n) { return (n + PHX_BLOCK - 1) / PHX_BLOCK; }
-void launch_generate(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t sample0, uint32_t num_samples) {
-  const uint32_t npaths = pb.num_pixels * num_samples;
-  hipLaunchKernelGGL(k_generate, dim3(blocks_for(npaths)), dim3(PHX_BLOCK), 0, stream, sc, pb, sample0, num_samples);
+void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples) {
+  hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(1), 0, stream, pb, num_samples);
 }
 void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
-                  int camera_rays) {
+                  int camera_rays, uint32_t sample0) {
   static const int gmul = getenv("PHX_TRACE_GRID") ? atoi(getenv("PHX_TRACE_GRID")) : 4;
   static const int gmul0 = getenv("PHX_TRACE_GRID0") ? atoi(getenv("PHX_TRACE_GRID0")) : 16;
   static const int inter0 = getenv("PHX_TRACE_INTER0") ? atoi(getenv("PHX_TRACE_INTER0")) : 1;
@@ -500,21 +518,26 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   const uint32_t need = (((capacity + block - 1) / block + 7u) / 8u) * 8u;
   grid = std::max(8u, std::min(grid, need));
   const dim3 g(grid), b(block);
-  static bool attr_set = false;
-  if (!attr_set) {  // allow the full 160 KB of LDS as dynamic shared memory
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  auto go = [&](auto kernel) {
+    static bool attr_set = false;  // one flag per instantiation: allow the full 160 KB of LDS as dynamic shared memory
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks, sample0);
+  };
+  if (camera_rays) {
+    if (block == 256) go(&k_trace<256, true>); else if (block == 512) go(&k_trace<512, true>); else go(&k_trace<1024, true>);
+  } else {
+    if (block == 256) go(&k_trace<256, false>); else if (block == 512) go(&k_trace<512, false>); else go(&k_trace<1024, false>);
   }
-  if (block == 256) hipLaunchKernelGGL(k_trace<256>, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks);
-  else if (block == 512) hipLaunchKernelGGL(k_trace<512>, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks);
-  else hipLaunchKernelGGL(k_trace<1024>, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks);
 }
-void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0) {
+void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays) {
   const dim3 g((capacity + PHX_SHADE_BLOCK - 1) / PHX_SHADE_BLOCK), b(PHX_SHADE_BLOCK);
-  if (sc.diffuse_only) hipLaunchKernelGGL(k_shade<true>, g, b, 0, stream, sc, pb, q, sq, sample0);
-  else hipLaunchKernelGGL(k_shade<false>, g, b, 0, stream, sc, pb, q, sq, sample0);
+  if (sc.diffuse_only) {
+    if (camera_rays) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+  } else {
+    if (camera_rays) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+  }
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
   hipLaunchKernelGGL(k_film, dim3(blocks_for(pb.num_pixels)), dim3(PHX_BLOCK), 0, stream, pb, num_samples, inv);
