@@ -209,7 +209,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 // Dynamic LDS layout: [ntop nodelets x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
 template <int BLOCK, bool GEN>
 __global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
-                                                 int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0) {
+                                                 int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t gmul, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * 5u);
@@ -228,10 +228,18 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, in
     // short queues: fewer, longer slices (at least min_chunks 64-ray chunks per workgroup) keep lanes refilled
     // instead of spreading a handful of rays over every resident wave
     const uint32_t chunks = (n + 63u) >> 6, per_xcd = (chunks + 7u) >> 3;
-    const uint32_t per_slot = max((per_xcd + nslots - 1u) / nslots, min_chunks);
+    // The grid is gmul x the resident workgroups (balance for long queues).  A queue too short to give every workgroup of
+    // that grid target_chunks chunks is cut into fewer, longer slices — but never fewer than the resident workgroups — so
+    // that a lane is refilled ~16 times per launch instead of 2-3 times (what a rank of an 8-GPU job sees at every bounce).
+    auto slice = [&](uint32_t total, uint32_t parts) {
+      uint32_t per = (total + parts - 1u) / parts;
+      if (per < target_chunks) per = min(target_chunks, (total + parts / gmul - 1u) / max(parts / gmul, 1u));
+      return max(per, min_chunks);
+    };
+    const uint32_t per_slot = slice(per_xcd, nslots);
     uint32_t c0, c1;
     if (interleave) {  // plain contiguous slices in launch order: image regions of different cost spread over all XCDs
-      const uint32_t per_blk = max((chunks + gridDim.x - 1u) / gridDim.x, min_chunks);
+      const uint32_t per_blk = slice(chunks, gridDim.x);
       c0 = min(blockIdx.x * per_blk, chunks); c1 = min(c0 + per_blk, chunks);
     } else {
       c0 = min(xcd * per_xcd + slot * per_slot, chunks);
@@ -508,20 +516,22 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   static const uint32_t block = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 256u;
   static const uint32_t ntop_req = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 73u;
   static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
+  static const uint32_t target_chunks = getenv("PHX_TARGET_CHUNKS") ? (uint32_t)atoi(getenv("PHX_TARGET_CHUNKS")) : 32u;
   // stack entries needed = BVH depth - 1 (one pending sibling group per level)
   const uint32_t levels = std::max(2u, sc.stack_levels);
   const uint32_t ntop = std::min(ntop_req, sc.num_nodes);
   const uint32_t lds = ntop * 80u + levels * block * 8u + 16u;
   const uint32_t wg_per_cu = std::max(1u, std::min({160u * 1024u / lds, 2048u / block, 512u * 64u * 4u / (64u * block)}));
   const int interleave = camera_rays ? inter0 : 0;
-  uint32_t grid = sc.num_cus * wg_per_cu * (uint32_t)(camera_rays ? gmul0 : gmul);
+  const uint32_t mul = (uint32_t)std::max(1, camera_rays ? gmul0 : gmul);
+  uint32_t grid = sc.num_cus * wg_per_cu * mul;
   const uint32_t need = (((capacity + block - 1) / block + 7u) / 8u) * 8u;
   grid = std::max(8u, std::min(grid, need));
   const dim3 g(grid), b(block);
   auto go = [&](auto kernel) {
     static bool attr_set = false;  // one flag per instantiation: allow the full 160 KB of LDS as dynamic shared memory
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks, sample0);
+    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks, sample0, mul, target_chunks);
   };
   if (camera_rays) {
     if (block == 256) go(&k_trace<256, true>); else if (block == 512) go(&k_trace<512, true>); else go(&k_trace<1024, true>);
