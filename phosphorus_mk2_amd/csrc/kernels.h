@@ -43,7 +43,7 @@ struct DevScene {
 };
 
 // counters: [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity)
-enum { CNT_SHADOW = 2, CNT_WORDS = 8 };
+enum { CNT_SHADOW = 2, CNT_CURSOR = 4, CNT_WORDS = 8 };
 struct DevStats { unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples; };
 
 struct PassBuffers {

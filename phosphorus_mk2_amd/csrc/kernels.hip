@@ -70,6 +70,7 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers
 __global__ void k_begin_pass(PassBuffers pb, uint32_t num_samples) {
   const uint32_t npaths = pb.num_pixels * num_samples;
   pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + 1] = 0;
+  pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + 1] = 0;
   atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
 }
 
@@ -94,10 +95,17 @@ struct LdsStack {
 // its closest-hit range; the any-hit / closest-hit distinction is a per-lane flag, so a launch has a single
 // drain phase (the tail where rays run out and lanes idle) instead of one per queue.
 #define PHX_STEPS_PER_REFILL 1
-template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */>
+#define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
+struct DynQueue {            // DYN: the launch is persistent and every WAVE pulls chunks of both queues on its own
+  uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
+  uint32_t wave_id, num_waves;
+  uint32_t* cursor;          // pb.counters + CNT_CURSOR: two global cursors, zeroed by the kernel that filled the queues
+};
+template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */, bool DYN>
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
                                              uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t refill_min,
-                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0) {
+                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0,
+                                             const DynQueue dq) {
   const uint32_t lane = __lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   bool active = false, any = false;
@@ -108,15 +116,38 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
+  uint32_t dlo = 0, dhi = 0, dfirst = 3u;  // DYN: the wave's current chunk [dlo, dhi) and "first chunk not yet taken" bits
   for (;;) {
     // ---- refill idle lanes from the workgroup's cursors
     const unsigned long long idle = __ballot(!active);
     if (phase < 2u && (uint32_t)__popcll(idle) >= refill_min) {
       const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
-      const uint32_t hi = phase == 0u ? shi : chi;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&cursor[phase], (uint32_t)__popcll(idle));
-      base = __shfl(base, (int)leader);
+      uint32_t hi, base;
+      if (DYN) {
+        if (dlo >= dhi) {  // chunk used up: the first one is the wave's by position, later ones come from the global cursor
+          const uint32_t c = phase == 0u ? dq.c0 : dq.c1, qn = phase == 0u ? dq.n0 : dq.n1;
+          uint32_t nb = 0;
+          if (dfirst & (1u << phase)) { dfirst = PHX_UNI(dfirst & ~(1u << phase)); nb = dq.wave_id * c; }
+          else {
+            if (lane == leader) nb = atomicAdd(&dq.cursor[phase], c) + dq.num_waves * c;
+            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nb, (int)leader));
+          }
+          if (nb >= qn) {  // this queue is exhausted
+            phase = PHX_UNI(phase + 1u);
+            if (phase < 2u || __ballot(active) != 0ull) { if (phase < 2u) continue; } else break;
+          } else { dlo = PHX_UNI(nb); dhi = PHX_UNI(min(nb + c, qn)); }
+        }
+        if (phase >= 2u) { hi = 0; base = 0; }
+        else {
+          const uint32_t take = PHX_UNI(min((uint32_t)__popcll(idle), dhi - dlo));
+          base = dlo; hi = dlo + take; dlo = PHX_UNI(dlo + take);
+        }
+      } else {
+        hi = phase == 0u ? shi : chi;
+        base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[phase], (uint32_t)__popcll(idle));
+        base = __shfl(base, (int)leader);
+      }
       if (!active) {
         const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
         if (my < hi) {
@@ -137,7 +168,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           active = true;
         }
       }
-      if (base + (uint32_t)__popcll(idle) >= hi) ++phase;  // this range is used up (wave-uniform)
+      if (!DYN && base + (uint32_t)__popcll(idle) >= hi) ++phase;  // this range is used up (wave-uniform)
       if (phase < 2u && __ballot(active) == 0ull) continue;  // nothing in flight yet: go fetch from the next range
     }
     if (!__ballot(active)) break;
@@ -203,12 +234,17 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 
 // Trace kernel: closest-hit rays of ray queue `q` (if do_closest) and any-hit rays of the shadow queue `sq`
 // filled by the previous k_shade (if do_shadow) in ONE launch, so that late bounces with few rays still fill
-// the chip.  Queue lengths are only known on the device: the grid is a fixed multiple of the resident
-// workgroups and every workgroup owns one contiguous range of each queue.  The split is XCD-aware:
-// workgroups b, b+8, ... share an XCD and its L2, so each XCD gets a contiguous eighth of the queue.
+// the chip.  Queue lengths are only known on the device.
+//   DYN (default): the launch is persistent — exactly the resident workgroups — and every WAVE pulls chunks of <= 256 rays
+//   from two global cursors: its first chunk is its own by position (no atomic), later ones cost one returning atomic per
+//   256 rays (~45/us at the baseline frame, under the ~90/us one address sustains; 64-ray chunks are atomic-bound).  A wave
+//   drains once per launch, not once per slice, and a slow image region is shared by everyone: -6 % trace time.
+//   !DYN: the grid is a fixed multiple of the resident workgroups and every workgroup owns one contiguous range of each
+//   queue, refilled through an LDS cursor.  The split is XCD-aware: workgroups b, b+8, ... share an XCD and its L2, so
+//   each XCD gets a contiguous eighth of the queue.
 // Dynamic LDS layout: [ntop nodelets x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
-template <int BLOCK, bool GEN>
-__global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
+template <int BLOCK, bool GEN, bool DYN>
+__global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
                                                  int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t gmul, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
@@ -248,16 +284,27 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DevScene sc, PassBuffers pb, in
     lo = c0 << 6; hi = min(c1 << 6, n);
     if (hi < lo) hi = lo;
   };
-  uint32_t slo, shi, clo, chi;
-  range(n_shadow, slo, shi);
-  range(n_closest, clo, chi);
-  if (shi <= slo && chi <= clo) return;  // nothing for this workgroup (uniform)
+  uint32_t slo = 0, shi = 0, clo = 0, chi = 0;
+  DynQueue dq{};
+  if (DYN) {
+    if (n_shadow == 0u && n_closest == 0u) return;
+    dq.n0 = n_shadow; dq.n1 = n_closest;
+    dq.num_waves = gridDim.x * (BLOCK / 64); dq.wave_id = blockIdx.x * (BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // tell the compiler it is wave-uniform
+    dq.cursor = pb.counters + CNT_CURSOR;
+    // ~min_chunks chunks per wave for mid-size queues, 64 .. target_chunks*64 rays each
+    auto chunk_of = [&](uint32_t n) { return min(max((n / (dq.num_waves * max(min_chunks, 1u)) + 63u) & ~63u, 64u), target_chunks * 64u); };
+    dq.c0 = chunk_of(n_shadow); dq.c1 = chunk_of(n_closest);
+  } else {
+    range(n_shadow, slo, shi);
+    range(n_closest, clo, chi);
+    if (shi <= slo && chi <= clo) return;  // nothing for this workgroup (uniform)
+  }
   // stage the top of the tree (nodes are stored breadth-first: the first ntop nodes ARE the top levels)
   const uint4* g4 = reinterpret_cast<const uint4*>(sc.nodes);
   for (uint32_t i = threadIdx.x; i < ntop * 5u; i += BLOCK) top[i] = g4[i];
   if (threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
   __syncthreads();
-  trace_stream<BLOCK, GEN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0);
+  trace_stream<BLOCK, GEN, DYN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0, dq);
 }
 
 template <int LEVELS, bool ANY>
@@ -292,6 +339,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q];
   uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
+  if (i == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + 1] = 0; }  // the next k_trace pulls its chunks from here
   if (blockIdx.x * PHX_SHADE_BLOCK >= count) return;
   if (!DIFFUSE_ONLY) {
     // Bucket the workgroup's 512 hits by material before shading them — what deferred_shading_kernel_t does per
@@ -513,17 +561,20 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   static const int gmul0 = getenv("PHX_TRACE_GRID0") ? atoi(getenv("PHX_TRACE_GRID0")) : 16;
   static const int inter0 = getenv("PHX_TRACE_INTER0") ? atoi(getenv("PHX_TRACE_INTER0")) : 1;
   static const uint32_t refill = getenv("PHX_REFILL") ? (uint32_t)atoi(getenv("PHX_REFILL")) : 8u;
-  static const uint32_t block = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 256u;
+  static const int dyn = getenv("PHX_TRACE_DYN") ? atoi(getenv("PHX_TRACE_DYN")) : 1;
+  static const int dyn_grid = getenv("PHX_TRACE_DYN_GRID") ? atoi(getenv("PHX_TRACE_DYN_GRID")) : 1;
+  static const uint32_t block = dyn ? 256u : (getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 256u);
   static const uint32_t ntop_req = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 73u;
   static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
-  static const uint32_t target_chunks = getenv("PHX_TARGET_CHUNKS") ? (uint32_t)atoi(getenv("PHX_TARGET_CHUNKS")) : 32u;
+  // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
+  static const uint32_t target_chunks = getenv("PHX_TARGET_CHUNKS") ? (uint32_t)atoi(getenv("PHX_TARGET_CHUNKS")) : (getenv("PHX_TRACE_DYN") && atoi(getenv("PHX_TRACE_DYN")) == 0 ? 32u : 4u);
   // stack entries needed = BVH depth - 1 (one pending sibling group per level)
   const uint32_t levels = std::max(2u, sc.stack_levels);
   const uint32_t ntop = std::min(ntop_req, sc.num_nodes);
   const uint32_t lds = ntop * 80u + levels * block * 8u + 16u;
   const uint32_t wg_per_cu = std::max(1u, std::min({160u * 1024u / lds, 2048u / block, 512u * 64u * 4u / (64u * block)}));
   const int interleave = camera_rays ? inter0 : 0;
-  const uint32_t mul = (uint32_t)std::max(1, camera_rays ? gmul0 : gmul);
+  const uint32_t mul = (uint32_t)std::max(1, dyn ? dyn_grid : (camera_rays ? gmul0 : gmul));
   uint32_t grid = sc.num_cus * wg_per_cu * mul;
   const uint32_t need = (((capacity + block - 1) / block + 7u) / 8u) * 8u;
   grid = std::max(8u, std::min(grid, need));
@@ -533,10 +584,12 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks, sample0, mul, target_chunks);
   };
-  if (camera_rays) {
-    if (block == 256) go(&k_trace<256, true>); else if (block == 512) go(&k_trace<512, true>); else go(&k_trace<1024, true>);
+  if (dyn) {
+    if (camera_rays) go(&k_trace<256, true, true>); else go(&k_trace<256, false, true>);
+  } else if (camera_rays) {
+    if (block == 256) go(&k_trace<256, true, false>); else if (block == 512) go(&k_trace<512, true, false>); else go(&k_trace<1024, true, false>);
   } else {
-    if (block == 256) go(&k_trace<256, false>); else if (block == 512) go(&k_trace<512, false>); else go(&k_trace<1024, false>);
+    if (block == 256) go(&k_trace<256, false, false>); else if (block == 512) go(&k_trace<512, false, false>); else go(&k_trace<1024, false, false>);
   }
 }
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays) {
