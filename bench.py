@@ -4,7 +4,7 @@
 A step = one whole frame (xpu_t::start ... join, the reference's own "Rendering time" bracket,
 src/core.cpp:158-177) of the synthetic workload:
   N=1 : Soup(100k) 1280x720 256 spp, depth 9, pps 1   (BASELINE.json configs[1])
-  N>1 : the same frame, its 32x32 tiles interleaved over the ranks (tile i -> rank i % N), every rank
+  N>1 : the same frame, its 32x32 tiles interleaved over the ranks (tile (tx, ty) -> rank (tx + 3 ty) % N), every rank
         accumulating into its own zero-initialised device film, one RCCL reduce(sum) of the film to
         rank 0 inside the timed region ("strong" scaling: total work is fixed).
 value = rays traced by ALL ranks (closest-hit + non-masked shadow rays) / max-over-ranks time.
@@ -187,7 +187,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "
                                    "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
-                       "tiles": "32x32, tile i -> rank i % n_gpus", "film_collective": "reduce(sum) to rank 0" if use_dist else "none",
+                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0" if use_dist else "none",
                        "rays_per_step": rays_total / args.steps, "camera_samples_per_step": W * H * args.spp,
                        "preprocess_s": preprocess_s, "bvh_builder": args.bvh_builder, "bvh_build_ms": st["bvh_build_ms"],
                        "bvh_bytes": st["bvh_bytes"], "film_mean": float(film[..., :3].mean()),

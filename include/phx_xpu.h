@@ -206,7 +206,8 @@ int         phx_dev_get_stats(const phx_device* dev, phx_stats* out);
 
 /* ---- native tile queue: job::tiles_t (src/jobs/tiles.hpp:10-90) ----------------------- */
 /* make(): row-major tile_size x tile_size tiles with edge remainders (tiles.hpp:49-89);
- * rank/world shard the queue for multi-GPU: tile i belongs to rank (i % world). */
+ * rank/world shard the queue for multi-GPU: tile (tx, ty) belongs to rank (tx + s*ty) % world, s the smallest odd
+ * number >= 3 coprime to world (diagonals over the film: balanced whatever the row length). */
 typedef struct phx_tiles phx_tiles;
 phx_tiles*  phx_tiles_make(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t world);
 int         phx_tiles_next(void* tiles /* phx_tiles* */, phx_tile* out); /* a phx_next_tile_fn */

@@ -2,7 +2,7 @@
 
 The reference has a single parallelism strategy — data parallelism over image tiles through a shared
 atomic tile cursor (src/jobs/tiles.hpp:40-47, src/xpu/cpu.cpp:223-238).  Across GPUs the cursor becomes
-a static interleave (tile i -> rank i % world: deterministic, and with the counter-based sampler the
+a static interleave (tile (tx, ty) -> rank (tx + s*ty) % world, diagonals over the film: deterministic, and with the counter-based sampler the
 image does not depend on the GPU count), every rank accumulates into its own zero-initialised film and
 the films are summed onto rank 0 with one reduce — `backend="nccl"` is RCCL over xGMI on ROCm; the
 same code runs on `gloo` for the CPU tests.  Disjoint tiles make the sum exact (x + 0).
@@ -13,13 +13,22 @@ import os
 def shard_tiles(width, height, tile_size, rank, world):
     """The tiles of job::tiles_t::make (src/jobs/tiles.hpp:49-89) that belong to `rank`."""
     out = []
-    i = 0
-    for y in range(0, height, tile_size):
-        for x in range(0, width, tile_size):
-            if i % world == rank:
+    s = tile_shift(world)
+    for ty, y in enumerate(range(0, height, tile_size)):
+        for tx, x in enumerate(range(0, width, tile_size)):
+            if (tx + s * ty) % world == rank:
                 out.append((x, y, min(tile_size, width - x), min(tile_size, height - y)))
-            i += 1
     return out
+
+
+def tile_shift(world):
+    """owner of tile (tx, ty) = (tx + s*ty) mod world with s the smallest odd number >= 3 coprime to world: diagonals over the
+    whole film instead of the vertical stripes "tile id mod world" gives when the row length is a multiple of world."""
+    import math
+    s = 3
+    while math.gcd(s, world) != 1:
+        s += 2
+    return s
 
 
 def init_process_group(backend, rank, world, device=None):

@@ -78,7 +78,7 @@ class Options:
 
 class Tiles:
     """job::tiles_t: precomputed tile_size x tile_size tiles behind an atomic cursor; `rank`/`world`
-    keep only the tiles of one GPU (tile i -> rank i % world) for the multi-GPU shard."""
+    keep only the tiles of one GPU (tile (tx, ty) -> rank (tx + s*ty) % world, see dist.tile_shift) for the multi-GPU shard."""
 
     def __init__(self, handle, lib, width, height):
         self._h, self._lib, self.width, self.height = handle, lib, width, height
