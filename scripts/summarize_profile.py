@@ -21,7 +21,8 @@ dst = os.path.join(root, "profiles")
 
 
 def kname(s):
-    return s.split("(")[0].replace("void phx::", "").replace("phx::", "")
+    """kernel name without arguments and without template arguments: the instantiations of k_trace / k_shade are summed"""
+    return s.split("(")[0].replace("void phx::", "").replace("phx::", "").split("<")[0]
 
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
