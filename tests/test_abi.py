@@ -73,6 +73,20 @@ def test_tile_queue_matches_reference_layout(lib):
         xpu.Tiles.make(64, 64, 32, rank=2, world=2)
 
 
+def test_tile_shard_is_balanced_and_not_striped(lib):
+    """the multi-GPU shard: every rank gets its fair share of tiles and touches every tile column and row band of the
+    baseline film (plain 'tile id mod world' gives vertical stripes at 40 tiles per row)"""
+    from phosphorus_mk2_amd import dist
+    for world in (2, 3, 4, 6, 8):
+        counts = []
+        for r in range(world):
+            mine = dist.shard_tiles(1280, 720, 32, r, world)
+            counts.append(len(mine))
+            assert len({x for x, _, _, _ in mine}) == 40, (world, r)
+            assert len({y for _, y, _, _ in mine}) == 23, (world, r)
+        assert sum(counts) == 40 * 23 and max(counts) - min(counts) <= 23, (world, counts)
+
+
 def test_no_silent_cpu_fallback(lib):
     """Without a visible MI355X the device cannot be made; nothing renders on the host instead."""
     from phosphorus_mk2_amd import xpu
