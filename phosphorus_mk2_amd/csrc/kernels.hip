@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
       if (FIRST && pb.pn) pb.pn[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       masked = true;  // a miss still occupies a (MASKED|SHADOW) slot in the reference's shadow stream (spt.hpp:138-141)
     }
-    pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));
+    if (alive) pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));  // only the next k_shade of a surviving path reads it
     if (FIRST) {  // r = 0 + beta * e: every path's radiance is written here, nothing is read
       const v3 rad = v3(0.0f) + v3(bd.x, bd.y, bd.z) * add_e;
       pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
