@@ -207,6 +207,42 @@ def soup(n, seed=1234, width=1280, height=720, fov=1.9, light=True, materials=No
     return SceneDesc(meshes, mats, CameraDesc(width, height, fov), name=f"soup{n}")
 
 
+def stress(seed=7, width=64, height=64):
+    """Geometry chosen to break builders and box tests, not to look like anything: a small soup + zero-area triangles
+    (collinear, repeated vertices) + ten coincident copies of each of 20 triangles (exact distance ties: the lowest
+    primitive index must win) + a chain whose sizes fall from 1 to 2^-20 ("teapot in a stadium") + triangles with
+    coordinates up to 1e4 + axis-aligned flat triangles (boxes of zero extent).  One grey material, the soup's light."""
+    rng = np.random.default_rng(seed)
+    def rnd(n, scale, centre=(0.0, 0.0, -2.5)):
+        c = rng.uniform(-0.9, 0.9, (n, 1, 3)) + np.array(centre)
+        return (c + rng.uniform(-scale, scale, (n, 3, 3))).astype(np.float32)
+    parts = [rnd(600, 0.12)]
+    deg = rnd(200, 0.2)
+    deg[:100, 2] = deg[:100, 1]                                             # repeated vertex
+    deg[100:, 2] = (0.25 * deg[100:, 0] + 0.75 * deg[100:, 1]).astype(np.float32)  # (nearly) collinear
+    parts.append(deg)
+    parts.append(np.repeat(rnd(20, 0.3), 10, axis=0))                          # coincident copies, interleaved below
+    chain = np.zeros((63, 3, 3), np.float32)
+    for k in range(63):
+        sz = np.float32(2.0 ** -(k % 21))
+        base = np.array([-0.9 + 0.028 * k, -0.5, -2.0 - 0.01 * k], np.float32)
+        chain[k] = base + sz * np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.25]], np.float32)
+    parts.append(chain)
+    parts.append((rnd(50, 1.0) * np.float32(1.0e4)).astype(np.float32))        # far away and huge
+    flat = rnd(120, 0.25)
+    flat[:40, :, 0] = flat[:40, :1, 0]; flat[40:80, :, 1] = flat[40:80, :1, 1]; flat[80:, :, 2] = flat[80:, :1, 2]
+    parts.append(flat)
+    verts = np.concatenate(parts).astype(np.float32)
+    order = rng.permutation(len(verts))                                        # shuffle primitive ids
+    verts = verts[order]
+    n = len(verts)
+    faces = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
+    mats = [diffuse(0.73, 0.73, 0.73), emitter(*LE)]
+    meshes = [MeshDesc(vertices=verts.reshape(-1, 3), faces=faces, sets=[(0, np.arange(n, dtype=np.uint32))]),
+              _quad((-2.0, 1.5, -0.5), (-2.0, 1.5, -4.5), (2.0, 1.5, -4.5), (2.0, 1.5, -0.5), 1)]
+    return SceneDesc(meshes, mats, CameraDesc(width, height, 1.9), name="stress")
+
+
 def smooth_blobs(width=96, height=64, per_vertex=True):
     """Smooth-shaded geometry for the interpolated-normal path of mesh_t::shading_parameters
     (src/mesh.cpp:187-199): two subdivided octahedra ("blobs") with per-vertex normals — or per-face-corner

@@ -202,6 +202,27 @@ def test_device_built_bvh_matches_host_built(xpu, orc, name, n):
     assert max_pixel_l2(devb, ref) < L2_TOL and bits_equal(devb[..., :3], ref[..., :3])
 
 
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_stress_geometry(xpu, orc, builder):
+    """zero-area, coincident (exact distance ties), 2^-20-sized, 1e4-sized and flat triangles: both builders must give the
+    oracle's distances bit for bit, ties resolved to the lowest primitive index, and the oracle's film"""
+    from phosphorus_mk2_amd import scenes
+    from test_host_bvh8 import check_hits_modulo_ties, stress_rays
+    sc = scenes.stress()
+    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder=builder))[0]
+    dev.preprocess(sc)
+    O = orc.Oracle(sc, spp=1)
+    o, d, tm = stress_rays(sc, 8000, 5)
+    check_hits_modulo_ties(dev.trace(o, d, tm), O.trace(o, d, tm, brute=True), min_ties=100)
+    tm2 = np.full(len(tm), 0.6, np.float32)
+    assert np.array_equal(dev.trace(o, d, tm2, shadow=True)["hit"], O.trace(o, d, tm2, shadow=True, brute=True)["hit"])
+    dev.close()
+    film, st = xpu.render(sc, spp=8, seed=2, bvh_builder=builder)
+    ref, ost = orc.Oracle(sc, spp=8, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=2, threads=8)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+    assert max_pixel_l2(film, ref) < L2_TOL and bits_equal(film[..., :3], ref[..., :3])
+
+
 def _room_scene():
     """the scene examples/render_room.c builds in C, through the Python mirror"""
     from phosphorus_mk2_amd import abi, scenes
