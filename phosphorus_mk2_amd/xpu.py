@@ -152,6 +152,21 @@ class Film:
         return self.data[..., :3]
 
 
+class BottomUpFilm(Film):
+    """The Blender-style sink (plugins/blender/sink.cpp:34-69): the host's (0,0) is the BOTTOM-left pixel, so a tile lands at
+    row `height - h - y` with its rows reversed, and the alpha of channel "primary" is set to one (sink.cpp:61-63).
+    Needs the add_tile callback path (FrameState.native_sink = False): the flip happens per tile, as in the reference."""
+
+    def add_tile(self, x, y, w, h, buffer, xstride, ystride):
+        src = np.ctypeslib.as_array(buffer, shape=(h * ystride,)).reshape(h, w, xstride)
+        inv_y = self.height - h - y
+        with self._lock:
+            self.data[inv_y:inv_y + h, x:x + w, :] = src[::-1]
+            if self.primary_components == 4:
+                self.data[inv_y:inv_y + h, x:x + w, 3] = 1.0
+            self.tiles += 1
+
+
 class FrameState:
     """frame_state_t (src/state.hpp:18-31).  `sampler_seed` replaces the shared sampler_t."""
 

@@ -23,3 +23,19 @@ def test_yaml_obj_scene_loads_and_renders(tmp_path, orc):
     assert np.isfinite(film).all() and film[..., :3].max() > 0.1
     sceneio.save_pfm(str(tmp_path / "out.pfm"), film)
     assert open(tmp_path / "out.pfm", "rb").read(16).startswith(b"PF\n64 48\n")
+
+
+def test_bottom_up_film_sink_flips_tiles_like_the_blender_sink():
+    """plugins/blender/sink.cpp:34-69: tile (x, y) lands at row height-h-y, rows reversed, primary alpha = 1"""
+    import ctypes as C
+    from phosphorus_mk2_amd import xpu
+    W, H = 8, 6
+    top, bottom = xpu.Film(W, H, 4), xpu.BottomUpFilm(W, H, 4)
+    rng = np.random.default_rng(0)
+    for (x, y, w, h) in [(0, 0, 4, 4), (4, 0, 4, 4), (0, 4, 4, 2), (4, 4, 4, 2)]:
+        tile = rng.random((h, w, 4)).astype(np.float32)
+        ptr = tile.ctypes.data_as(C.POINTER(C.c_float))
+        top.add_tile(x, y, w, h, ptr, 4, 4 * w)
+        bottom.add_tile(x, y, w, h, ptr, 4, 4 * w)
+    assert np.array_equal(bottom.data[..., :3], top.data[::-1, :, :3])
+    assert (bottom.data[..., 3] == 1.0).all() and bottom.tiles == 4
