@@ -340,3 +340,19 @@ def test_full_size_properties(xpu, orc):
     ref, _ = O.render(rng=orc.RNG_COUNTER, seed=1, threads=8, tiles=tiles)
     for (x, y, w, h) in tiles:
         assert bits_equal(film[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3])
+
+
+def test_4k_film_in_several_batches(xpu, orc):
+    """BASELINE config #4 shape of the film (3840x2160: more pixels than one tile batch holds, so the frame is rendered in
+    several batches) with the normals channel on; tiles from every batch are compared with the oracle bit for bit."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(20000, width=3840, height=2160)
+    film, st = xpu.render(sc, spp=2, seed=9, normals=True, native_sink=True)
+    assert film.shape == (2160, 3840, 7) and np.isfinite(film).all()
+    assert st["camera_samples"] == 3840 * 2160 * 2 and st["tiles"] == 120 * 68
+    O = orc.Oracle(sc, spp=2)
+    tiles = [(32 * x, 32 * y, 32, 32 if y < 67 else 16) for y in (0, 33, 34, 66, 67) for x in (0, 59, 119)]
+    img, _, nrm = O.render(rng=orc.RNG_COUNTER, seed=9, threads=8, tiles=tiles, normals=True)
+    for (x, y, w, h) in tiles:
+        assert bits_equal(film[y:y + h, x:x + w, :3], img[y:y + h, x:x + w, :3])
+        assert bits_equal(film[y:y + h, x:x + w, 4:7], nrm[y:y + h, x:x + w, :])
