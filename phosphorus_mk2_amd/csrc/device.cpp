@@ -80,6 +80,7 @@ struct phx_device {
   DevBuf<float4> ro[2], rd[2], hit, so, sd, sc, pb, pr, pn;
   DevBuf<uint32_t> counters; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
   float* h_acc = nullptr; size_t h_acc_n = 0;  // pinned staging for add_tile
+  std::vector<phx_tile> pix_xy_tiles;          // the tiles pix_xy currently describes
 
   // frame
   phx_frame frame{};
@@ -574,14 +575,17 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   if (npaths >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");
   const uint32_t xs = frame.primary_components + (frame.normals_channel ? 3u : 0u);
 
-  std::vector<uint32_t> xy(P);
-  {
+  // pixel table of the batch; a frame loop presents the same tiles again and again, so the upload is skipped when nothing changed
+  if (tiles.size() != pix_xy_tiles.size() || std::memcmp(tiles.data(), pix_xy_tiles.data(), tiles.size() * sizeof(phx_tile)) != 0) {
+    std::vector<uint32_t> xy(P);
     uint32_t k = 0;
     for (auto& t : tiles)
       for (uint32_t y = 0; y < t.h; ++y)
         for (uint32_t x = 0; x < t.w; ++x) xy[k++] = (t.x + x) | ((t.y + y) << 16);
+    pix_xy_tiles.clear();
+    if ((rc = pix_xy.upload(xy))) return rc;
+    pix_xy_tiles = tiles;
   }
-  if ((rc = pix_xy.upload(xy))) return rc;
   for (int q = 0; q < 2; ++q) if ((rc = ro[q].alloc(npaths)) || (rc = rd[q].alloc(npaths))) return rc;
   if ((rc = hit.alloc(npaths)) || (rc = so.alloc(npaths)) || (rc = sd.alloc(npaths)) || (rc = sc.alloc(npaths)) ||
       (rc = pb.alloc(npaths)) || (rc = pr.alloc(npaths)) || (rc = acc.alloc((size_t)P * xs))) return rc;
@@ -636,13 +640,28 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     }
     HIPCHK(hipMemcpyAsync(h_acc, acc.p, nfl * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    size_t off = 0;
-    for (auto& t : tiles) {
-      if (frame.add_tile) frame.add_tile(frame.film_user, (int32_t)t.x, (int32_t)t.y, (int32_t)t.w, (int32_t)t.h, h_acc + off, xs, xs * t.w);
-      if (frame.host_film)
-        for (uint32_t y = 0; y < t.h; ++y)
-          std::memcpy(frame.host_film + ((size_t)(t.y + y) * scene.width + t.x) * xs, h_acc + off + (size_t)y * t.w * xs, (size_t)t.w * xs * sizeof(float));
-      off += (size_t)t.w * t.h * xs;
+    std::vector<size_t> offs(tiles.size() + 1, 0);
+    for (size_t i = 0; i < tiles.size(); ++i) offs[i + 1] = offs[i] + (size_t)tiles[i].w * tiles[i].h * xs;
+    if (frame.add_tile)
+      for (size_t i = 0; i < tiles.size(); ++i) {
+        const phx_tile& t = tiles[i];
+        frame.add_tile(frame.film_user, (int32_t)t.x, (int32_t)t.y, (int32_t)t.w, (int32_t)t.h, h_acc + offs[i], xs, xs * t.w);
+      }
+    if (frame.host_film) {  // what an add_tile that copies into a frame buffer does, spread over a few host threads
+      auto copy_range = [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+          const phx_tile& t = tiles[i];
+          for (uint32_t y = 0; y < t.h; ++y)
+            std::memcpy(frame.host_film + ((size_t)(t.y + y) * scene.width + t.x) * xs, h_acc + offs[i] + (size_t)y * t.w * xs, (size_t)t.w * xs * sizeof(float));
+        }
+      };
+      const size_t nthreads = std::min<size_t>({8, std::max(1u, std::thread::hardware_concurrency() / 2), (nfl * sizeof(float)) >> 20});
+      if (nthreads <= 1) copy_range(0, tiles.size());
+      else {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < nthreads; ++k) pool.emplace_back(copy_range, tiles.size() * k / nthreads, tiles.size() * (k + 1) / nthreads);
+        for (auto& th : pool) th.join();
+      }
     }
   } else {
     HIPCHK(hipStreamSynchronize(stream));
