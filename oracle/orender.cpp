@@ -379,11 +379,27 @@ struct tile_renderer_t {
   }
 
   void trace_rays(interactions_t& out) {  // cpu.cpp:148-154
-    trace(false);
-    shade(out);
-    prepare_occlusion_queries(out);
-    trace(true);
-    integrate(out);
+    static const bool prof = getenv("ORC_PROFILE") != nullptr;
+    if (!prof) {
+      trace(false);
+      shade(out);
+      prepare_occlusion_queries(out);
+      trace(true);
+      integrate(out);
+      return;
+    }
+    using clk = std::chrono::steady_clock;
+    static double acc[5] = {0, 0, 0, 0, 0}; static uint64_t calls = 0;  // diagnostic only: single-threaded runs
+    auto t0 = clk::now(); trace(false);
+    auto t1 = clk::now(); shade(out);
+    auto t2 = clk::now(); prepare_occlusion_queries(out);
+    auto t3 = clk::now(); trace(true);
+    auto t4 = clk::now(); integrate(out);
+    auto t5 = clk::now();
+    acc[0] += std::chrono::duration<double>(t1 - t0).count(); acc[1] += std::chrono::duration<double>(t2 - t1).count();
+    acc[2] += std::chrono::duration<double>(t3 - t2).count(); acc[3] += std::chrono::duration<double>(t4 - t3).count();
+    acc[4] += std::chrono::duration<double>(t5 - t4).count();
+    if ((++calls & 1023) == 0) std::fprintf(stderr, "orc profile: trace %.3f shade %.3f nee %.3f shadow-trace %.3f integrate %.3f s\n", acc[0], acc[1], acc[2], acc[3], acc[4]);
   }
 
   void render_tile(const phx_tile& tile, float* film, float* normals) {  // cpu.cpp:156-205
