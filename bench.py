@@ -153,7 +153,7 @@ def main():
             dev.join()  # join() synchronises the device's stream
             pdist.reduce_film(film_dev, dst=0)  # the single film collective (RCCL over xGMI)
         else:
-            film_host.data[:] = 0
+            # no clearing: at world 1 the device's tiles cover (and overwrite) every pixel of the host film
             dev.start(scene, xpu.FrameState(args.seed, tiles, film_host, native_sink=True))
             dev.join()
         return dev.stats()
