@@ -47,7 +47,7 @@ def parse():
     p.add_argument("--samples-in-flight", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-tiles", type=int, default=100000, help="tiles of the frame in the CPU baseline sample")
-    p.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel in the CPU baseline sample")
+    p.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel in the CPU baseline sample")
     p.add_argument("--bvh-builder", choices=["host", "device"], default="host", help="host binned SAH (default) or device LBVH")
     p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
     return p.parse_args()
@@ -74,13 +74,13 @@ def cpu_baseline(scene, args):
                   f"{rays} rays in {st['seconds']:.2f} s",
     }
     # one thread, the reference's sequential mt19937 draw order (the mode its own threads cannot scale in)
-    t1 = all_tiles[len(all_tiles) // 2::max(1, len(all_tiles) // 16)][:8]
-    _, s1 = O.render(rng=orc.RNG_SEQ, seed=args.seed, threads=1, tiles=t1, sample_begin=0, sample_end=min(2, args.cpu_spp))
+    t1 = all_tiles[len(all_tiles) // 4::max(1, len(all_tiles) // 32)][:16]
+    _, s1 = O.render(rng=orc.RNG_SEQ, seed=args.seed, threads=1, tiles=t1, sample_begin=0, sample_end=min(16, args.cpu_spp))
     r1 = s1["rays_closest"] + s1["rays_shadow"]
     out["single_thread"] = {"value": r1 / s1["seconds"] / 1e6, "unit": "Mrays/s", "rng": "sequential mt19937, reference draw order",
-                            "sample": f"{len(t1)} tiles x {min(2, args.cpu_spp)} spp, {r1} rays in {s1['seconds']:.2f} s"}
+                            "sample": f"{len(t1)} tiles x {min(16, args.cpu_spp)} spp, {r1} rays in {s1['seconds']:.2f} s"}
     # context, not measured here: the AVX2 reference itself traced this soup at 1.30 Mrays/s on one thread and 3.57 Mrays/s
-    # on eight in the survey's container; the scalar bit-exact port is several times slower per thread
+    # on eight in the survey's container; the port traces with the same 8-lane AVX2 arithmetic (oracle/obvh.h)
     out["reference_context"] = "BASELINE.md: reference AVX2 build, 100 k soup 1280x720 4 spp: 1.30 Mrays/s (1 thread), 3.57 Mrays/s (8 threads)"
     vn_c = st["node_visits_closest"] / max(1, st["rays_closest"]); vl_c = st["packet_visits_closest"] / max(1, st["rays_closest"])
     vn_s = st["node_visits_shadow"] / max(1, st["rays_shadow"]); vl_s = st["packet_visits_shadow"] / max(1, st["rays_shadow"])

@@ -10,6 +10,9 @@
 //     Moeller-Trumbore iterate_rays / iterate_triangles (src/accel/triangle.hpp:126-287)
 //   * brute force: linear_mbvh_kernel_t (src/kernels/cpu/linear_bvh_kernel.cpp:14-19)
 // Counters (node visits, packet visits) define V_n / V_l of SURVEY §8(d).
+// The slab test and the triangle test exist twice: spelled out for one child box / one triangle (the readable
+// restatement), and on 8 AVX2 lanes — the shape the reference itself uses — which is the default because it is what
+// bench.py times as the CPU baseline.  Both perform the same IEEE operations in the same order (bit-identical, tested).
 #pragma once
 #include "oscene.h"
 
@@ -17,6 +20,7 @@
 #include <cstring>
 #include <vector>
 #if defined(__x86_64__)
+#include <immintrin.h>
 #include <xmmintrin.h>
 #endif
 
@@ -25,10 +29,15 @@ namespace orc {
 static const uint32_t F_HIT = 1, F_MASKED = 2, F_SHADOW = 4, F_SPECULAR = 8;  // state.hpp:33-36
 
 // numeric modes (SURVEY §7 hard part 2)
+inline int& scalar_default() { static int v = 0; return v; }  // process-wide default of modes_t::scalar (orc_set_scalar)
 struct modes_t {
   int rcp_approx = 0;   // 1: use the x86 RCPPS approximation where the reference does (this CPU only)
   int slab_literal = 0; // 1: reference slab test verbatim; 0: conservative (padded) slab test — never
                         //    loses a Moeller-Trumbore hit, so results do not depend on BVH topology
+  int scalar = scalar_default();  // 1: one child box / one triangle at a time (the spelled-out restatement); 0: the same arithmetic
+                        //    on 8 lanes with AVX2, as the reference's own simd::intersect<8> / moeller_trumbore_t<8> do.
+                        //    Every lane performs the same IEEE operations in the same order, so the two are bit-identical
+                        //    (tests/test_oracle_render.py::test_simd_and_scalar_restatements_agree).
 };
 
 struct node8_t {  // node.hpp:12-35
@@ -304,6 +313,74 @@ inline bool slab_conservative(const node8_t& n, int c, const V3& o, const V3& oo
   return nn <= ff;
 }
 
+// ---- the same two tests on 8 lanes (AVX2) ------------------------------------------------------------------
+// One ray x the 8 child boxes of a node: bit i of the result = child i is hit, dist8[i] = its (unpadded) entry distance.
+inline unsigned slab8(const node8_t& n, const V3& o, const V3& ood, float d, bool literal, float* dist8) {
+  const __m256 minx = _mm256_loadu_ps(n.bounds), miny = _mm256_loadu_ps(n.bounds + 8), minz = _mm256_loadu_ps(n.bounds + 16);
+  const __m256 maxx = _mm256_loadu_ps(n.bounds + 24), maxy = _mm256_loadu_ps(n.bounds + 32), maxz = _mm256_loadu_ps(n.bounds + 40);
+  const bool gx = ood.x >= 0.0f, gy = ood.y >= 0.0f, gz = ood.z >= 0.0f;
+  const __m256 ox = _mm256_set1_ps(o.x), oy = _mm256_set1_ps(o.y), oz = _mm256_set1_ps(o.z);
+  const __m256 rx = _mm256_set1_ps(ood.x), ry = _mm256_set1_ps(ood.y), rz = _mm256_set1_ps(ood.z);
+  const __m256 nx = _mm256_mul_ps(_mm256_sub_ps(gx ? minx : maxx, ox), rx), fx = _mm256_mul_ps(_mm256_sub_ps(gx ? maxx : minx, ox), rx);
+  const __m256 ny = _mm256_mul_ps(_mm256_sub_ps(gy ? miny : maxy, oy), ry), fy = _mm256_mul_ps(_mm256_sub_ps(gy ? maxy : miny, oy), ry);
+  const __m256 nz = _mm256_mul_ps(_mm256_sub_ps(gz ? minz : maxz, oz), rz), fz = _mm256_mul_ps(_mm256_sub_ps(gz ? maxz : minz, oz), rz);
+  const __m256 zero = _mm256_setzero_ps(), dd = _mm256_set1_ps(d);
+  __m256 nn, ff;
+  if (literal) {  // simd_max / simd_min are _mm256_max_ps / _mm256_min_ps
+    nn = _mm256_max_ps(_mm256_max_ps(nx, ny), _mm256_max_ps(nz, zero));
+    ff = _mm256_min_ps(_mm256_min_ps(fx, fy), _mm256_min_ps(fz, dd));
+    _mm256_storeu_ps(dist8, nn);
+  } else {        // IEEE maxNum / minNum: the non-NaN operand wins (max_ps returns its second operand when either is NaN)
+    auto maxnum = [](__m256 a, __m256 b) { return _mm256_blendv_ps(_mm256_max_ps(a, b), a, _mm256_cmp_ps(b, b, _CMP_UNORD_Q)); };
+    auto minnum = [](__m256 a, __m256 b) { return _mm256_blendv_ps(_mm256_min_ps(a, b), a, _mm256_cmp_ps(b, b, _CMP_UNORD_Q)); };
+    nn = maxnum(maxnum(nx, ny), maxnum(nz, zero));
+    ff = minnum(minnum(fx, fy), minnum(fz, dd));
+    _mm256_storeu_ps(dist8, nn);
+    const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7fffffff)), eps = _mm256_set1_ps(4.76837158203125e-7f);
+    nn = _mm256_sub_ps(nn, _mm256_mul_ps(_mm256_and_ps(nn, absmask), eps));
+    ff = _mm256_add_ps(ff, _mm256_mul_ps(_mm256_and_ps(ff, absmask), eps));
+  }
+  return (unsigned)_mm256_movemask_ps(_mm256_cmp_ps(nn, ff, _CMP_LE_OQ));
+}
+
+// One ray x the (up to) 8 triangles of a packet: mt_test on 8 lanes, then the closest-of-packet selection in lane order.
+inline void packet_vs_ray_simd(const packet8_t& pk, rays_t& R, uint32_t index) {
+  const V3 o = R.p(index), wi = R.wi(index);
+  const __m256 e0x = _mm256_loadu_ps(pk.e0x), e0y = _mm256_loadu_ps(pk.e0y), e0z = _mm256_loadu_ps(pk.e0z);
+  const __m256 e1x = _mm256_loadu_ps(pk.e1x), e1y = _mm256_loadu_ps(pk.e1y), e1z = _mm256_loadu_ps(pk.e1z);
+  const __m256 wx = _mm256_set1_ps(wi.x), wy = _mm256_set1_ps(wi.y), wz = _mm256_set1_ps(wi.z);
+  const __m256 tx = _mm256_sub_ps(_mm256_set1_ps(o.x), _mm256_loadu_ps(pk.v0x));
+  const __m256 ty = _mm256_sub_ps(_mm256_set1_ps(o.y), _mm256_loadu_ps(pk.v0y));
+  const __m256 tz = _mm256_sub_ps(_mm256_set1_ps(o.z), _mm256_loadu_ps(pk.v0z));
+  // sv::cross(a, b) = (msub(a.y,b.z, a.z*b.y), msub(a.z,b.x, a.x*b.z), msub(a.x,b.y, a.y*b.x)); sv::dot = madd(ax,bx, madd(ay,by, az*bz))
+  const __m256 px = _mm256_fmsub_ps(wy, e1z, _mm256_mul_ps(wz, e1y)), py = _mm256_fmsub_ps(wz, e1x, _mm256_mul_ps(wx, e1z)),
+               pz = _mm256_fmsub_ps(wx, e1y, _mm256_mul_ps(wy, e1x));
+  const __m256 det = _mm256_fmadd_ps(e0x, px, _mm256_fmadd_ps(e0y, py, _mm256_mul_ps(e0z, pz)));
+  const __m256 ood = _mm256_div_ps(_mm256_set1_ps(1.0f), det);
+  const __m256 qx = _mm256_fmsub_ps(ty, e0z, _mm256_mul_ps(tz, e0y)), qy = _mm256_fmsub_ps(tz, e0x, _mm256_mul_ps(tx, e0z)),
+               qz = _mm256_fmsub_ps(tx, e0y, _mm256_mul_ps(ty, e0x));
+  const __m256 us = _mm256_mul_ps(_mm256_fmadd_ps(tx, px, _mm256_fmadd_ps(ty, py, _mm256_mul_ps(tz, pz))), ood);
+  const __m256 vs = _mm256_mul_ps(_mm256_fmadd_ps(wx, qx, _mm256_fmadd_ps(wy, qy, _mm256_mul_ps(wz, qz))), ood);
+  const __m256 ds = _mm256_mul_ps(_mm256_fmadd_ps(e1x, qx, _mm256_fmadd_ps(e1y, qy, _mm256_mul_ps(e1z, qz))), ood);
+  const __m256 zero = _mm256_setzero_ps(), one = _mm256_set1_ps(1.0f), eps = _mm256_set1_ps(0.00000001f);
+  const __m256 xmask = _mm256_or_ps(_mm256_cmp_ps(det, eps, _CMP_GT_OQ), _mm256_cmp_ps(det, _mm256_sub_ps(zero, eps), _CMP_LT_OQ));
+  const __m256 umask = _mm256_cmp_ps(us, zero, _CMP_GE_OQ);
+  const __m256 vmask = _mm256_and_ps(_mm256_cmp_ps(vs, zero, _CMP_GE_OQ), _mm256_cmp_ps(_mm256_add_ps(us, vs), one, _CMP_LE_OQ));
+  const __m256 dmask = _mm256_and_ps(_mm256_cmp_ps(ds, zero, _CMP_GE_OQ), _mm256_cmp_ps(ds, _mm256_set1_ps(R.d[index]), _CMP_LT_OQ));
+  unsigned m = (unsigned)_mm256_movemask_ps(_mm256_and_ps(_mm256_and_ps(vmask, umask), _mm256_and_ps(dmask, xmask)));
+  m &= pk.num >= 8 ? 0xffu : ((1u << pk.num) - 1u);
+  if (!m) return;
+  float u8[8], v8[8], d8[8];
+  _mm256_storeu_ps(u8, us); _mm256_storeu_ps(v8, vs); _mm256_storeu_ps(d8, ds);
+  float closest = R.d[index]; int idx = -1;
+  for (int j = 0; j < 8; ++j)
+    if (((m >> j) & 1u) && d8[j] < closest) { closest = d8[j]; idx = j; }
+  if (idx != -1) {
+    if (!R.is_shadow(index)) { R.mesh[index] = pk.meshid[idx]; R.face[index] = pk.faceid[idx]; R.u[index] = u8[idx]; R.v[index] = v8[idx]; R.prim[index] = pk.prim[idx]; }
+    R.flags[index] |= F_HIT; R.d[index] = closest;
+  }
+}
+
 // MBVH-RS stream traversal over R[0..num) (stream_bvh_kernel.cpp:18-148).  Slots are traced
 // unless MASKED (lanes_t::init, stream.hpp:25-32).
 struct stream_tracer_t {
@@ -340,10 +417,19 @@ struct stream_tracer_t {
           const V3 o = R.p(ray), w = R.wi(ray);
           V3 ood = modes.rcp_approx ? V3(rcp_approx(w.x), rcp_approx(w.y), rcp_approx(w.z)) : V3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
           ++ctr.node_visits;
-          for (int c = 0; c < 8; ++c) {
-            float dist;
-            bool h = modes.slab_literal ? slab_literal(node, c, o, ood, R.d[ray], dist) : slab_conservative(node, c, o, ood, R.d[ray], dist);
-            if (h) { num_active[c] += 1; length[c] += dist; lanes[c].push_back(ray); }
+          if (modes.scalar) {
+            for (int c = 0; c < 8; ++c) {
+              float dist;
+              bool h = modes.slab_literal ? slab_literal(node, c, o, ood, R.d[ray], dist) : slab_conservative(node, c, o, ood, R.d[ray], dist);
+              if (h) { num_active[c] += 1; length[c] += dist; lanes[c].push_back(ray); }
+            }
+          } else {
+            float dist8[8];
+            unsigned hm = slab8(node, o, ood, R.d[ray], modes.slab_literal != 0, dist8);
+            while (hm) {
+              const int c = __builtin_ctz(hm); hm &= hm - 1;
+              num_active[c] += 1; length[c] += dist8[c]; lanes[c].push_back(ray);
+            }
           }
         }
         // insertion sort of the hit children by summed entry distance, :99-115 (verbatim: the
@@ -368,7 +454,10 @@ struct stream_tracer_t {
           uint32_t index = cur.offset; uint32_t prims = 0;
           do {
             if (index < bvh->packets.size()) {  // guard for the empty-leaf quirk (count 0 leaves)
-              for (size_t r = 0; r < nr; ++r) { ++ctr.packet_visits; packet_vs_ray(bvh->packets[index], R, todo[begin + r]); }
+              for (size_t r = 0; r < nr; ++r) {
+                ++ctr.packet_visits;
+                if (modes.scalar) packet_vs_ray(bvh->packets[index], R, todo[begin + r]); else packet_vs_ray_simd(bvh->packets[index], R, todo[begin + r]);
+              }
             }
             prims += 8; ++index;
           } while (prims < cur.prims);

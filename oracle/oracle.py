@@ -96,6 +96,12 @@ def make_options(spp=16, pps=1, depth=9, **kw):
     return o
 
 
+def set_scalar(on):
+    """1: trace one child box / one triangle at a time; 0 (default): the same arithmetic on 8 AVX2 lanes.  Bit-identical
+    (tests/test_oracle_render.py::test_simd_and_scalar_restatements_agree); applies to tracers created afterwards."""
+    load().orc_set_scalar(1 if on else 0)
+
+
 class Oracle:
     """One scene loaded into the CPU restatement (reference-layout BVH built on creation)."""
 

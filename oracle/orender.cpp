@@ -450,6 +450,9 @@ void add_stats(stats_t& a, const stats_t& b) {
 
 extern "C" {
 
+// 1: trace with the one-lane-at-a-time restatement, 0 (default): the same arithmetic on 8 AVX2 lanes (obvh.h, modes_t::scalar)
+void orc_set_scalar(int on) { scalar_default() = on; }
+
 void* orc_create(const phx_scene* scene, const phx_options* options) {
   oracle_t* o = new oracle_t();
   if (!o->scene.load(scene) || !options) { delete o; return nullptr; }

@@ -4,6 +4,7 @@ and the committed regression film still reproduces."""
 import os
 
 import numpy as np
+import pytest
 
 from conftest import ROOT, bits_equal
 
@@ -82,3 +83,34 @@ def test_regression_film(orc):
     ref = np.load(os.path.join(ROOT, "tests", "golden", "oracle_cornell_32x32_spp4.npy"))
     a, _ = orc.Oracle(scenes.cornell(32, 32), spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=2)
     assert bits_equal(a[..., :3], ref)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "soup", "stress"])
+def test_simd_and_scalar_restatements_agree(orc, scene_name):
+    """obvh.h traces 8 child boxes / 8 triangles per AVX2 instruction by default; modes_t::scalar spells the same arithmetic
+    out one lane at a time.  Films, ray counts, BVH visit counters and ray-dump traces must be identical, in the
+    conservative and in the literal slab test."""
+    from conftest import bits_equal, random_rays
+    from phosphorus_mk2_amd import scenes
+    sc = {"cornell": lambda: scenes.cornell(48, 48), "soup": lambda: scenes.soup(3000, width=64, height=48), "stress": lambda: scenes.stress(width=48, height=48)}[scene_name]()
+    o, d, tm = random_rays(4000, 21)
+    d[:50] = np.eye(3, dtype=np.float32)[np.arange(50) % 3] * np.float32(-1.0)  # axis-parallel rays: 0 * inf in the slab test
+    out = {}
+    try:
+        for scalar in (1, 0):
+            orc.set_scalar(scalar)
+            O = orc.Oracle(sc, spp=3, pps=1, depth=6)
+            for literal in (0, 1):
+                img, st = O.render(rng=orc.RNG_COUNTER, seed=5, threads=2, slab_literal=literal)
+                tr = O.trace(o, d, tm, slab_literal=literal)
+                sh = O.trace(o, d, np.full(len(tm), 0.5, np.float32), shadow=True, slab_literal=literal)
+                out[(scalar, literal)] = (img.copy(), {k: v for k, v in st.items() if k != "seconds"}, tr, sh)
+    finally:
+        orc.set_scalar(0)
+    for literal in (0, 1):
+        a, b = out[(1, literal)], out[(0, literal)]
+        assert bits_equal(a[0], b[0]) and a[1] == b[1]
+        for k in ("t", "u", "v"):
+            assert bits_equal(a[2][k], b[2][k])
+        assert np.array_equal(a[2]["prim"], b[2]["prim"]) and np.array_equal(a[3]["hit"], b[3]["hit"])
+        assert a[2]["node_visits"] == b[2]["node_visits"] and a[2]["packet_visits"] == b[2]["packet_visits"]
