@@ -390,6 +390,7 @@ struct stream_tracer_t {
   std::vector<uint32_t> lane_num;  // unused; lanes[i].size() is the fill
   struct task_t { uint32_t offset, num_rays, lane, flags, prims; };
   std::vector<task_t> tasks;
+  std::vector<V3> inv_dir;
   trace_counters_t ctr;
 
   explicit stream_tracer_t(const bvh8_t* b, modes_t m = modes_t()) : bvh(b), modes(m) {}
@@ -397,7 +398,13 @@ struct stream_tracer_t {
   void trace(rays_t& R, uint32_t num) {
     for (auto& l : lanes) l.clear();
     tasks.clear();
-    for (uint32_t i = 0; i < num; ++i) if (!R.is_masked(i)) lanes[0].push_back(i);
+    // 1/dir is a function of the ray alone: computed once here instead of at every node visit (same values)
+    inv_dir.resize(num);
+    for (uint32_t i = 0; i < num; ++i) if (!R.is_masked(i)) {
+      lanes[0].push_back(i);
+      const V3 w = R.wi(i);
+      inv_dir[i] = modes.rcp_approx ? V3(rcp_approx(w.x), rcp_approx(w.y), rcp_approx(w.z)) : V3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
+    }
     ctr.rays += lanes[0].size();
     if (lanes[0].empty() || !bvh->has_root) return;
     tasks.push_back(task_t{0, (uint32_t)lanes[0].size(), 0, 0, 0});
@@ -414,8 +421,8 @@ struct stream_tracer_t {
         float length[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t ray : todo) {
           if (R.is_shadow(ray) && R.is_hit(ray)) continue;  // any-hit early out, :61-64
-          const V3 o = R.p(ray), w = R.wi(ray);
-          V3 ood = modes.rcp_approx ? V3(rcp_approx(w.x), rcp_approx(w.y), rcp_approx(w.z)) : V3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
+          const V3 o = R.p(ray);
+          const V3 ood = inv_dir[ray];
           ++ctr.node_visits;
           if (modes.scalar) {
             for (int c = 0; c < 8; ++c) {
