@@ -105,3 +105,34 @@ def save_pfm(path, rgb):
     with open(path, "wb") as f:
         f.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
         f.write(img.tobytes())
+
+
+def save_exr(path, film):
+    """film::file_t::finalize (src/film/file.cpp:27-46) writes the 4-component float image as OpenEXR through OpenImageIO;
+    this writes the same image as an uncompressed scanline OpenEXR 2 file (FLOAT channels A, B, G, R; a film without
+    alpha gets A = 1) with nothing but numpy.  `film`: H x W x (3|4+) float32, row 0 = top row."""
+    import struct
+    img = np.asarray(film, np.float32)
+    h, w = img.shape[:2]
+    planes = {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2],
+              "A": img[..., 3] if img.shape[2] >= 4 else np.ones((h, w), np.float32)}
+    names = sorted(planes)  # the channel list is sorted by name and so is the data of a scanline
+
+    def attr(name, typ, value):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in names) + b"\0"  # 2 = FLOAT
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    header = (struct.pack("<ii", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", b"\0") +
+              attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") +
+              attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) +
+              attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    row_bytes = 4 * w * len(names)
+    first = len(header) + 8 * h
+    offsets = first + (8 + row_bytes) * np.arange(h, dtype=np.uint64)
+    rows = np.stack([np.ascontiguousarray(planes[n], "<f4") for n in names], axis=1)  # h x channels x w
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(offsets.astype("<u8").tobytes())
+        for y in range(h):
+            f.write(struct.pack("<ii", y, row_bytes))
+            f.write(rows[y].tobytes())

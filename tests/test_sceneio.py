@@ -39,3 +39,37 @@ def test_bottom_up_film_sink_flips_tiles_like_the_blender_sink():
         bottom.add_tile(x, y, w, h, ptr, 4, 4 * w)
     assert np.array_equal(bottom.data[..., :3], top.data[::-1, :, :3])
     assert (bottom.data[..., 3] == 1.0).all() and bottom.tiles == 4
+
+
+def test_exr_writer_round_trips_through_a_minimal_reader(tmp_path):
+    """uncompressed scanline OpenEXR: magic, sorted FLOAT channel list, one offset per scanline, channel-planar rows"""
+    import struct
+    from phosphorus_mk2_amd import sceneio
+    rng = np.random.default_rng(3)
+    film = rng.random((5, 7, 4)).astype(np.float32)
+    p = str(tmp_path / "film.exr")
+    sceneio.save_exr(p, film)
+    b = open(p, "rb").read()
+    assert struct.unpack_from("<ii", b, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        (size,) = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<iiii", attrs["dataWindow"][1]) == (0, 0, 6, 4)
+    ch, q, names = attrs["channels"][1], 0, []
+    while ch[q] != 0:
+        e = ch.index(b"\0", q); names.append(ch[q:e].decode()); q = e + 1
+        assert struct.unpack_from("<iB3xii", ch, q) == (2, 0, 1, 1); q += 16
+    assert names == ["A", "B", "G", "R"]
+    offsets = struct.unpack_from("<5Q", b, pos)
+    back = np.zeros_like(film)
+    for y, off in enumerate(offsets):
+        yy, size = struct.unpack_from("<ii", b, off)
+        assert yy == y and size == 4 * 7 * 4
+        row = np.frombuffer(b, "<f4", 28, off + 8).reshape(4, 7)
+        back[y, :, 3], back[y, :, 2], back[y, :, 1], back[y, :, 0] = row[0], row[1], row[2], row[3]
+    assert np.array_equal(back, film) and offsets[-1] + 8 + 112 == len(b)
