@@ -326,6 +326,29 @@ def test_error_behaviour(xpu):
     dev.close()
 
 
+def test_one_device_many_scenes_and_frames(xpu):
+    """xpu_t::preprocess is called again for every scene (cpu.cpp:35-44 rebuilds the accelerator) and start/join once per
+    frame: a device that has rendered other scenes, film sizes and tile sets must give what a fresh device gives."""
+    from phosphorus_mk2_amd import scenes
+    a, b, c = scenes.cornell(96, 64), scenes.soup(4000, width=64, height=96), scenes.multi_material_soup(2000, width=64, height=64)
+    fresh = {id(s): xpu.render(s, spp=5, seed=3)[0] for s in (a, b, c)}
+    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=5, paths_per_sample=1))[0]
+    for s in (a, b, c, b, a):
+        dev.preprocess(s)
+        W, H = s.camera.width, s.camera.height
+        for rep in range(2):  # the second frame reuses the cached pixel table of the same tiles
+            film = xpu.Film(W, H, 4)
+            dev.start(s, xpu.FrameState(3, xpu.Tiles.make(W, H, 32), film))
+            dev.join()
+            assert bits_equal(film.data, fresh[id(s)])
+        half = xpu.Film(W, H, 4)  # other tiles on the same device: one rank's share of two
+        dev.start(s, xpu.FrameState(3, xpu.Tiles.make(W, H, 32, 1, 2), half))
+        dev.join()
+        mask = half.data[..., :3].sum(-1) != 0
+        assert mask.any() and bits_equal(half.data[mask], fresh[id(s)][mask])
+    dev.close()
+
+
 def test_full_size_properties(xpu, orc):
     """BASELINE config #2 shape (100k soup, 1280x720): ray accounting and a tile-subset comparison
     against the oracle (the oracle renders 40 tiles in seconds), at reduced spp."""
