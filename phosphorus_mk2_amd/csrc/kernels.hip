@@ -563,13 +563,21 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   static const uint32_t refill = getenv("PHX_REFILL") ? (uint32_t)atoi(getenv("PHX_REFILL")) : 8u;
   static const int dyn = getenv("PHX_TRACE_DYN") ? atoi(getenv("PHX_TRACE_DYN")) : 1;
   static const int dyn_grid = getenv("PHX_TRACE_DYN_GRID") ? atoi(getenv("PHX_TRACE_DYN_GRID")) : 1;
-  static const uint32_t block = dyn ? 256u : (getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 256u);
-  static const uint32_t ntop_req = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 73u;
+  // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
+  static const uint32_t block = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : (dyn ? 1024u : 256u);
+  static const uint32_t ntop_env = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 0u;
   static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
   // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
   static const uint32_t target_chunks = getenv("PHX_TARGET_CHUNKS") ? (uint32_t)atoi(getenv("PHX_TARGET_CHUNKS")) : (getenv("PHX_TRACE_DYN") && atoi(getenv("PHX_TRACE_DYN")) == 0 ? 32u : 4u);
   // stack entries needed = BVH depth - 1 (one pending sibling group per level)
   const uint32_t levels = std::max(2u, sc.stack_levels);
+  // nodelets staged in LDS: whatever the per-lane stacks leave of the workgroup's share of the CU's 160 KB at full occupancy
+  // (32 waves per CU); 9 (root + one level) when the stacks alone do not fit, and occupancy then follows from the LDS
+  uint32_t ntop_req = ntop_env;
+  if (!ntop_req) {
+    const uint32_t share = 160u * 1024u / (2048u / block), stacks = levels * block * 8u + 16u;
+    ntop_req = share > stacks + 9u * 80u ? (share - stacks) / 80u : 9u;
+  }
   const uint32_t ntop = std::min(ntop_req, sc.num_nodes);
   const uint32_t lds = ntop * 80u + levels * block * 8u + 16u;
   const uint32_t wg_per_cu = std::max(1u, std::min({160u * 1024u / lds, 2048u / block, 512u * 64u * 4u / (64u * block)}));
@@ -585,7 +593,8 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
     hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks, sample0, mul, target_chunks);
   };
   if (dyn) {
-    if (camera_rays) go(&k_trace<256, true, true>); else go(&k_trace<256, false, true>);
+    if (camera_rays) { if (block == 256) go(&k_trace<256, true, true>); else if (block == 512) go(&k_trace<512, true, true>); else go(&k_trace<1024, true, true>); }
+    else { if (block == 256) go(&k_trace<256, false, true>); else if (block == 512) go(&k_trace<512, false, true>); else go(&k_trace<1024, false, true>); }
   } else if (camera_rays) {
     if (block == 256) go(&k_trace<256, true, false>); else if (block == 512) go(&k_trace<512, true, false>); else go(&k_trace<1024, true, false>);
   } else {
