@@ -613,6 +613,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   for (uint32_t s0 = 0; s0 < spp; s0 += S) {
     const uint32_t ns = std::min(S, spp - s0);
     const uint32_t cap = P * ns;
+    B.num_samples = ns;
     if ((rc = timed_launch(2, [&]() { launch_begin_pass(stream, B, ns); }))) return rc;
     int q = 0;
     for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)

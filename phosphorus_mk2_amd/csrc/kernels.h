@@ -58,6 +58,7 @@ struct PassBuffers {
   const float2* jitter;       // per spp index: film jitter shared by all pixels (src/sampling.cpp:98-112)
   float* acc;                 // batch render buffer: tile after tile, interleaved xstride floats per pixel
   uint32_t num_pixels;        // P
+  uint32_t num_samples;       // samples of this pass; path id = pixel_in_batch * num_samples + sample_in_pass
   uint32_t xstride;
   uint32_t normals_offset;    // offset of channel "normals" inside a pixel, 0 = off
   uint64_t seed;

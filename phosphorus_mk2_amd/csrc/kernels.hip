@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, u
 // k_trace of a pass and the first k_shade both rebuild the ray of path `path` from the pixel table and the jitter table
 // (about 40 instructions) instead of writing and re-reading 32 B per path.
 __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers& pb, uint32_t path, uint32_t sample0, v3& p, v3& w) {
-  const uint32_t s = path / pb.num_pixels, pix = path - s * pb.num_pixels;
+  const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;  // pixel-major: a wave = 64 samples of one pixel
   const uint32_t xy = pb.pix_xy[pix];
   const float sx = (float)(xy & 0xffffu), sy = (float)(xy >> 16);
   const float2 jit = pb.jitter[sample0 + s];
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
     v3 add_e(0.0f); bool add_rad = false;
     const bool beta_finite = isfinite(bd.x) && isfinite(bd.y) && isfinite(bd.z);
     uint32_t depth = f2u(bd.w);
-    const uint32_t s = path / pb.num_pixels, pix = path - s * pb.num_pixels;
+    const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
     const uint32_t xy = pb.pix_xy[pix];
     const uint32_t key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
     const uint32_t tri = f2u(h.w);
@@ -503,21 +503,46 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
 }
 
 // ---- film -------------------------------------------------------------------------------------------
-// channels.primary->add(x, y, r * (1.0f / (spp * pps))) per sample, in sample order (cpu.cpp:175-198)
-__global__ void __launch_bounds__(PHX_BLOCK) k_film(PassBuffers pb, uint32_t num_samples, float inv) {
-  const uint32_t pix = blockIdx.x * PHX_BLOCK + threadIdx.x;
-  if (pix >= pb.num_pixels) return;
-  float* out = pb.acc + (size_t)pix * pb.xstride;
-  float r = out[0], g = out[1], b = out[2];
-  for (uint32_t s = 0; s < num_samples; ++s) {
-    const float4 c = pb.pr[(size_t)s * pb.num_pixels + pix];
-    r += c.x * inv; g += c.y * inv; b += c.z * inv;
-    if (pb.pn) {
-      const float4 n = pb.pn[(size_t)s * pb.num_pixels + pix];
-      if (n.w != 0.0f) { out[pb.normals_offset] = n.x; out[pb.normals_offset + 1] = n.y; out[pb.normals_offset + 2] = n.z; }
+// channels.primary->add(x, y, r * (1.0f / (spp * pps))) per sample, IN SAMPLE ORDER (cpu.cpp:175-198): the sum of a pixel is
+// a serial chain, so it cannot be a lane-parallel reduction.  Radiance is stored pixel-major (pix * S + s): a 256-thread
+// block moves 64 pixels x 16 samples at a time through LDS — read as 256-B runs of one pixel's samples, summed by the 64
+// threads that own a pixel each (row pitch 17 float4: conflict-free) — instead of every thread striding 16*S bytes.
+#define PHX_FILM_PIX 64
+#define PHX_FILM_SMP 16
+__global__ void __launch_bounds__(256) k_film(PassBuffers pb, uint32_t num_samples, float inv) {
+  __shared__ float4 tile[PHX_FILM_PIX * (PHX_FILM_SMP + 1)];
+  const uint32_t pix0 = blockIdx.x * PHX_FILM_PIX;
+  const uint32_t my_pix = pix0 + threadIdx.x;
+  const bool owner = threadIdx.x < PHX_FILM_PIX && my_pix < pb.num_pixels;
+  float r = 0.0f, g = 0.0f, b = 0.0f;
+  float* out = pb.acc + (size_t)my_pix * pb.xstride;
+  if (owner) { r = out[0]; g = out[1]; b = out[2]; }
+  float nx = 0.0f, ny = 0.0f, nz = 0.0f; bool have_n = false;
+  const int nsrc = pb.pn ? 2 : 1;
+  for (uint32_t s0 = 0; s0 < num_samples; s0 += PHX_FILM_SMP) {
+    for (int src = 0; src < nsrc; ++src) {
+      const float4* __restrict__ in = src ? pb.pn : pb.pr;
+      __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+      for (int k = 0; k < PHX_FILM_PIX * PHX_FILM_SMP / 256; ++k) {
+        const uint32_t e = k * 256 + threadIdx.x, p = e / PHX_FILM_SMP, sm = e % PHX_FILM_SMP;
+        if (pix0 + p < pb.num_pixels && s0 + sm < num_samples) tile[p * (PHX_FILM_SMP + 1) + sm] = in[(size_t)(pix0 + p) * num_samples + s0 + sm];
+      }
+      __syncthreads();
+      if (owner) {
+        const uint32_t cnt = min((uint32_t)PHX_FILM_SMP, num_samples - s0);
+        for (uint32_t sm = 0; sm < cnt; ++sm) {
+          const float4 c = tile[threadIdx.x * (PHX_FILM_SMP + 1) + sm];
+          if (src == 0) { r += c.x * inv; g += c.y * inv; b += c.z * inv; }
+          else if (c.w != 0.0f) { nx = c.x; ny = c.y; nz = c.z; have_n = true; }  // the last sample with a primary hit wins
+        }
+      }
     }
   }
-  out[0] = r; out[1] = g; out[2] = b;
+  if (owner) {
+    out[0] = r; out[1] = g; out[2] = b;
+    if (have_n) { out[pb.normals_offset] = nx; out[pb.normals_offset + 1] = ny; out[pb.normals_offset + 2] = nz; }
+  }
 }
 
 // batch render buffer -> full-frame device film (film_t::add_tile for a device-resident sink)
@@ -612,7 +637,7 @@ void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   }
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
-  hipLaunchKernelGGL(k_film, dim3(blocks_for(pb.num_pixels)), dim3(PHX_BLOCK), 0, stream, pb, num_samples, inv);
+  hipLaunchKernelGGL(k_film, dim3((pb.num_pixels + PHX_FILM_PIX - 1) / PHX_FILM_PIX), dim3(256), 0, stream, pb, num_samples, inv);
 }
 void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width) {
   hipLaunchKernelGGL(k_scatter_film, dim3(blocks_for(pb.num_pixels)), dim3(PHX_BLOCK), 0, stream, pb, device_film, film_width);
