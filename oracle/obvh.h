@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <limits>
 #include <vector>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -29,11 +30,16 @@ namespace orc {
 static const uint32_t F_HIT = 1, F_MASKED = 2, F_SHADOW = 4, F_SPECULAR = 8;  // state.hpp:33-36
 
 // numeric modes (SURVEY §7 hard part 2)
-inline int& scalar_default() { static int v = 0; return v; }  // process-wide default of modes_t::scalar (orc_set_scalar)
+inline int& scalar_default() { static int v = 0; return v; }
+inline int& tie_default() { static int v = 0; return v; }     // process-wide default of modes_t::tie_lowest_prim (orc_set_tie_rule)  // process-wide default of modes_t::scalar (orc_set_scalar)
 struct modes_t {
   int rcp_approx = 0;   // 1: use the x86 RCPPS approximation where the reference does (this CPU only)
   int slab_literal = 0; // 1: reference slab test verbatim; 0: conservative (padded) slab test — never
                         //    loses a Moeller-Trumbore hit, so results do not depend on BVH topology
+  int tie_lowest_prim = tie_default();  // 0 (the reference): of two triangles hit at bitwise the same distance the one met first
+                        //    wins (strict d < ray.d, triangle.hpp:158-164) — an accident of the tree's layout; 1: the one with the
+                        //    lower primitive index wins, which is what the device does (bvh8.h) and makes whole-frame
+                        //    comparisons exact.  Measured difference: 1 of 8.8 M rays of the 100 k soup at 4 spp.
   int scalar = scalar_default();  // 1: one child box / one triangle at a time (the spelled-out restatement); 0: the same arithmetic
                         //    on 8 lanes with AVX2, as the reference's own simd::intersect<8> / moeller_trumbore_t<8> do.
                         //    Every lane performs the same IEEE operations in the same order, so the two are bit-identical
@@ -255,13 +261,21 @@ inline bool mt_test(const packet8_t& pk, int j, const V3& o, const V3& wi, float
 }
 
 // packet vs. one ray, closest-of-packet by strict '<' in lane order (triangle.hpp:166-198)
-inline void packet_vs_ray(const packet8_t& pk, rays_t& R, uint32_t index) {
+inline void packet_vs_ray(const packet8_t& pk, rays_t& R, uint32_t index, bool tie = false) {
   const V3 o = R.p(index), wi = R.wi(index);
   float closest = R.d[index];
   int idx = -1; float bu = 0, bv = 0;
+  // tie rule (modes_t::tie_lowest_prim): a hit at exactly the current best distance replaces it if its primitive index is lower
+  bool have = tie && R.is_hit(index) && !R.is_shadow(index);
+  uint32_t best_prim = have ? R.prim[index] : 0u;
   for (int j = 0; j < (int)pk.num; ++j) {
     float us, vs, ds;
-    if (mt_test(pk, j, o, wi, R.d[index], us, vs, ds) && ds < closest) { closest = ds; idx = j; bu = us; bv = vs; }
+    if (!tie) {
+      if (mt_test(pk, j, o, wi, R.d[index], us, vs, ds) && ds < closest) { closest = ds; idx = j; bu = us; bv = vs; }
+    } else if (mt_test(pk, j, o, wi, std::numeric_limits<float>::infinity(), us, vs, ds) &&
+               (ds < closest || (have && ds == closest && pk.prim[j] < best_prim))) {
+      closest = ds; idx = j; bu = us; bv = vs; best_prim = pk.prim[j]; have = !R.is_shadow(index);
+    }
   }
   if (idx != -1) {
     if (!R.is_shadow(index)) { R.mesh[index] = pk.meshid[idx]; R.face[index] = pk.faceid[idx]; R.u[index] = bu; R.v[index] = bv; R.prim[index] = pk.prim[idx]; }
@@ -344,7 +358,7 @@ inline unsigned slab8(const node8_t& n, const V3& o, const V3& ood, float d, boo
 }
 
 // One ray x the (up to) 8 triangles of a packet: mt_test on 8 lanes, then the closest-of-packet selection in lane order.
-inline void packet_vs_ray_simd(const packet8_t& pk, rays_t& R, uint32_t index) {
+inline void packet_vs_ray_simd(const packet8_t& pk, rays_t& R, uint32_t index, bool tie = false) {
   const V3 o = R.p(index), wi = R.wi(index);
   const __m256 e0x = _mm256_loadu_ps(pk.e0x), e0y = _mm256_loadu_ps(pk.e0y), e0z = _mm256_loadu_ps(pk.e0z);
   const __m256 e1x = _mm256_loadu_ps(pk.e1x), e1y = _mm256_loadu_ps(pk.e1y), e1z = _mm256_loadu_ps(pk.e1z);
@@ -366,15 +380,20 @@ inline void packet_vs_ray_simd(const packet8_t& pk, rays_t& R, uint32_t index) {
   const __m256 xmask = _mm256_or_ps(_mm256_cmp_ps(det, eps, _CMP_GT_OQ), _mm256_cmp_ps(det, _mm256_sub_ps(zero, eps), _CMP_LT_OQ));
   const __m256 umask = _mm256_cmp_ps(us, zero, _CMP_GE_OQ);
   const __m256 vmask = _mm256_and_ps(_mm256_cmp_ps(vs, zero, _CMP_GE_OQ), _mm256_cmp_ps(_mm256_add_ps(us, vs), one, _CMP_LE_OQ));
-  const __m256 dmask = _mm256_and_ps(_mm256_cmp_ps(ds, zero, _CMP_GE_OQ), _mm256_cmp_ps(ds, _mm256_set1_ps(R.d[index]), _CMP_LT_OQ));
+  const __m256 dlim = _mm256_set1_ps(R.d[index]);
+  const __m256 dmask = _mm256_and_ps(_mm256_cmp_ps(ds, zero, _CMP_GE_OQ), tie ? _mm256_cmp_ps(ds, dlim, _CMP_LE_OQ) : _mm256_cmp_ps(ds, dlim, _CMP_LT_OQ));
   unsigned m = (unsigned)_mm256_movemask_ps(_mm256_and_ps(_mm256_and_ps(vmask, umask), _mm256_and_ps(dmask, xmask)));
   m &= pk.num >= 8 ? 0xffu : ((1u << pk.num) - 1u);
   if (!m) return;
   float u8[8], v8[8], d8[8];
   _mm256_storeu_ps(u8, us); _mm256_storeu_ps(v8, vs); _mm256_storeu_ps(d8, ds);
   float closest = R.d[index]; int idx = -1;
+  bool have = tie && R.is_hit(index) && !R.is_shadow(index);
+  uint32_t best_prim = have ? R.prim[index] : 0u;
   for (int j = 0; j < 8; ++j)
-    if (((m >> j) & 1u) && d8[j] < closest) { closest = d8[j]; idx = j; }
+    if (((m >> j) & 1u) && (d8[j] < closest || (have && d8[j] == closest && pk.prim[j] < best_prim))) {
+      closest = d8[j]; idx = j; best_prim = pk.prim[j]; have = tie && !R.is_shadow(index);
+    }
   if (idx != -1) {
     if (!R.is_shadow(index)) { R.mesh[index] = pk.meshid[idx]; R.face[index] = pk.faceid[idx]; R.u[index] = u8[idx]; R.v[index] = v8[idx]; R.prim[index] = pk.prim[idx]; }
     R.flags[index] |= F_HIT; R.d[index] = closest;
@@ -463,7 +482,8 @@ struct stream_tracer_t {
             if (index < bvh->packets.size()) {  // guard for the empty-leaf quirk (count 0 leaves)
               for (size_t r = 0; r < nr; ++r) {
                 ++ctr.packet_visits;
-                if (modes.scalar) packet_vs_ray(bvh->packets[index], R, todo[begin + r]); else packet_vs_ray_simd(bvh->packets[index], R, todo[begin + r]);
+                if (modes.scalar) packet_vs_ray(bvh->packets[index], R, todo[begin + r], modes.tie_lowest_prim != 0);
+                else packet_vs_ray_simd(bvh->packets[index], R, todo[begin + r], modes.tie_lowest_prim != 0);
               }
             }
             prims += 8; ++index;
@@ -475,10 +495,10 @@ struct stream_tracer_t {
 };
 
 // linear_mbvh_kernel_t: every non-masked ray against every packet (linear_bvh_kernel.cpp:14-19)
-inline void trace_brute(const bvh8_t& bvh, rays_t& R, uint32_t num) {
+inline void trace_brute(const bvh8_t& bvh, rays_t& R, uint32_t num, bool tie = false) {
   for (uint32_t i = 0; i < num; ++i) {
     if (R.is_masked(i)) continue;
-    for (const packet8_t& pk : bvh.packets) packet_vs_ray(pk, R, i);
+    for (const packet8_t& pk : bvh.packets) packet_vs_ray(pk, R, i, tie);
   }
 }
 

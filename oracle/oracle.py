@@ -102,6 +102,12 @@ def set_scalar(on):
     load().orc_set_scalar(1 if on else 0)
 
 
+def set_tie_rule(lowest_prim):
+    """0 (default, the reference): of two triangles hit at bitwise the same distance the one the traversal meets first wins;
+    1: the one with the lower primitive index wins — the device's rule (bvh8.h).  Applies to tracers created afterwards."""
+    load().orc_set_tie_rule(1 if lowest_prim else 0)
+
+
 class Oracle:
     """One scene loaded into the CPU restatement (reference-layout BVH built on creation)."""
 

@@ -452,6 +452,8 @@ extern "C" {
 
 // 1: trace with the one-lane-at-a-time restatement, 0 (default): the same arithmetic on 8 AVX2 lanes (obvh.h, modes_t::scalar)
 void orc_set_scalar(int on) { scalar_default() = on; }
+// 0 (default): equal-distance ties as in the reference (first met wins); 1: lowest primitive index wins, as on the device
+void orc_set_tie_rule(int lowest_prim) { tie_default() = lowest_prim; }
 
 void* orc_create(const phx_scene* scene, const phx_options* options) {
   oracle_t* o = new oracle_t();
@@ -544,7 +546,7 @@ int orc_trace(void* h, uint32_t n, const float* o3, const float* d3, const float
       R.wx[i] = d3[3 * g]; R.wy[i] = d3[3 * g + 1]; R.wz[i] = d3[3 * g + 2];
       R.d[i] = tmax[g]; R.flags[i] = flags_in ? flags_in[g] : 0;
     }
-    if (mode == 0) tr.trace(R, cnt); else trace_brute(o->bvh, R, cnt);
+    if (mode == 0) tr.trace(R, cnt); else trace_brute(o->bvh, R, cnt, md.tie_lowest_prim != 0);
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t g = base + i;
       t[g] = R.d[i]; u[g] = R.u[i]; v[g] = R.v[i]; prim[g] = R.prim[i]; flags_out[g] = R.flags[i];

@@ -213,7 +213,15 @@ def test_stress_geometry(xpu, orc, builder):
     dev.preprocess(sc)
     O = orc.Oracle(sc, spp=1)
     o, d, tm = stress_rays(sc, 8000, 5)
-    check_hits_modulo_ties(dev.trace(o, d, tm), O.trace(o, d, tm, brute=True), min_ties=100)
+    g = dev.trace(o, d, tm)
+    check_hits_modulo_ties(g, O.trace(o, d, tm, brute=True), min_ties=100)
+    orc.set_tie_rule(1)  # with the device's tie rule the oracle agrees on the primitive as well, brute force and stream traversal
+    try:
+        for brute in (True, False):
+            r = O.trace(o, d, tm, brute=brute)
+            assert np.array_equal(g["prim"], r["prim"]) and bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    finally:
+        orc.set_tie_rule(0)
     tm2 = np.full(len(tm), 0.6, np.float32)
     assert np.array_equal(dev.trace(o, d, tm2, shadow=True)["hit"], O.trace(o, d, tm2, shadow=True, brute=True)["hit"])
     dev.close()
@@ -350,19 +358,28 @@ def test_one_device_many_scenes_and_frames(xpu):
 
 
 def test_full_size_properties(xpu, orc):
-    """BASELINE config #2 shape (100k soup, 1280x720): ray accounting and a tile-subset comparison
-    against the oracle (the oracle renders 40 tiles in seconds), at reduced spp."""
+    """BASELINE config #2 (100k soup, 1280x720) at reduced spp: ray accounting, and the WHOLE frame — all 920 tiles — against
+    the oracle, bit for bit (the AVX2 oracle traces the 8.8 M rays of 4 spp in about a second on 16 threads)."""
     from phosphorus_mk2_amd import scenes
     sc = scenes.soup(100000)
     film, st = xpu.render(sc, spp=4, seed=1)
     assert film.shape == (720, 1280, 4) and np.isfinite(film).all()
     assert st["camera_samples"] == 1280 * 720 * 4
     assert st["rays_closest"] >= st["camera_samples"] and st["rays_shadow"] + st["rays_masked"] <= st["rays_closest"]
-    O = orc.Oracle(sc, spp=4)
-    tiles = [(32 * x, 32 * y, 32, 32 if y < 22 else 16) for y in (0, 7, 15, 22) for x in range(0, 40, 4)]
-    ref, _ = O.render(rng=orc.RNG_COUNTER, seed=1, threads=8, tiles=tiles)
-    for (x, y, w, h) in tiles:
-        assert bits_equal(film[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3])
+    # (a) the oracle with the device's tie rule (equal-distance hits go to the lowest primitive index): everything is exact
+    orc.set_tie_rule(1)
+    try:
+        ref, ost = orc.Oracle(sc, spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=16)
+    finally:
+        orc.set_tie_rule(0)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"]
+    assert max_pixel_l2(film, ref) < L2_TOL and bits_equal(film[..., :3], ref[..., :3])
+    # (b) the oracle as the reference resolves ties (first met wins, i.e. by the layout of ITS tree): the film is still within
+    # the north-star tolerance and the ray counts differ by at most a few rays in millions
+    ref0, ost0 = orc.Oracle(sc, spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=16)
+    assert max_pixel_l2(film, ref0) < L2_TOL
+    for k in ("rays_closest", "rays_shadow", "rays_masked"):
+        assert abs(st[k] - ost0[k]) <= 4, (k, st[k], ost0[k])
 
 
 def test_4k_film_in_several_batches(xpu, orc):

@@ -85,6 +85,14 @@ def test_stress_geometry_equals_brute_force(host_bvh8, orc):
     r = orc.Oracle(sc, spp=1).trace(o, d, tm, brute=True)
     check_hits_modulo_ties(g, r, min_ties=100)
     assert (g["prim"] != 0xffffffff).sum() > 2000
+    orc.set_tie_rule(1)  # the oracle with the device's tie rule: the primitive agrees too
+    try:
+        O = orc.Oracle(sc, spp=1)
+        for brute in (True, False):
+            r = O.trace(o, d, tm, brute=brute)
+            assert np.array_equal(g["prim"], r["prim"]) and bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    finally:
+        orc.set_tie_rule(0)
     host_bvh8.hb8_free(h)
 
 
