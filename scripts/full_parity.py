@@ -1,0 +1,24 @@
+"""The parity gate at FULL size: BASELINE config #2 (Soup(100 000), 1280x720, 256 spp, depth 9) rendered by the device and by
+the CPU oracle (all host threads), compared pixel by pixel.  Prints the max per-pixel L2 with the reference's tie rule and
+with the device's (lowest primitive index on exact distance ties), and the ray counts.  ~1 min on the GPU box."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from phosphorus_mk2_amd import scenes, xpu
+from oracle import oracle as orc
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+sc = scenes.soup(100000, seed=1234, width=1280, height=720)
+t0 = time.time(); film, st = xpu.render(sc, spp=spp, pps=1, depth=9, seed=1, native_sink=True); t_gpu = time.time() - t0
+out = {"spp": spp, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]]}
+for rule in (1, 0):
+    orc.set_tie_rule(rule)
+    t0 = time.time()
+    ref, ost = orc.Oracle(sc, spp=spp, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=1, threads=os.cpu_count())
+    d = film[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64)
+    out["device_tie_rule" if rule else "reference_tie_rule"] = {
+        "oracle_s": time.time() - t0, "oracle_rays": [ost["rays_closest"], ost["rays_shadow"], ost["rays_masked"]],
+        "max_pixel_l2": float(np.sqrt((d * d).sum(-1)).max()),
+        "pixels_differing": int((film[..., :3].view(np.uint32) != ref[..., :3].view(np.uint32)).any(-1).sum())}
+    print(json.dumps(out), flush=True)
+orc.set_tie_rule(0)
