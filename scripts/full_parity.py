@@ -8,9 +8,10 @@ from phosphorus_mk2_amd import scenes, xpu
 from oracle import oracle as orc
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-sc = scenes.soup(100000, seed=1234, width=1280, height=720)
+what = sys.argv[2] if len(sys.argv) > 2 else "100000"   # triangle count of the soup, or "cornell" (BASELINE config #1: 256x256)
+sc = scenes.cornell(256, 256) if what == "cornell" else scenes.soup(int(what), seed=1234, width=1280, height=720)
 t0 = time.time(); film, st = xpu.render(sc, spp=spp, pps=1, depth=9, seed=1, native_sink=True); t_gpu = time.time() - t0
-out = {"spp": spp, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]]}
+out = {"scene": sc.name, "spp": spp, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]]}
 for rule in (1, 0):
     orc.set_tie_rule(rule)
     t0 = time.time()
