@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -159,6 +160,16 @@ int bake_material(const phx_material& m, float sheen_L5, DevMaterial& out) {
   return 0;
 }
 
+// No C++ exception may cross the C ABI (the reference's own std::runtime_error cases become status codes): every entry
+// point that allocates or spawns runs its body through guarded().
+template <typename F>
+int guarded(F&& body) {
+  try { return body(); }
+  catch (const std::bad_alloc&) { return fail(PHX_ERR_OOM, "host memory allocation failed"); }
+  catch (const std::exception& e) { return fail(PHX_ERR_DEVICE, std::string("unexpected exception: ") + e.what()); }
+  catch (...) { return fail(PHX_ERR_DEVICE, "unexpected exception"); }
+}
+
 }  // namespace
 
 extern "C" {
@@ -195,7 +206,8 @@ phx_device* phx_dev_make(const phx_options* options) {
     return nullptr;
   }
   if (hipSetDevice(dev) != hipSuccess) { fail(PHX_ERR_DEVICE, "hipSetDevice failed"); return nullptr; }
-  phx_device* d = new phx_device();
+  phx_device* d = new (std::nothrow) phx_device();
+  if (!d) { fail(PHX_ERR_OOM, "host memory allocation failed"); return nullptr; }
   d->opt = *options; d->hip_device = dev;
   if (d->opt.samples_per_pixel == 0) d->opt.samples_per_pixel = 16;
   if (d->opt.paths_per_sample == 0) d->opt.paths_per_sample = 1;
@@ -210,7 +222,9 @@ void phx_dev_destroy(phx_device* dev) {
   delete dev;
 }
 
-int phx_dev_preprocess(phx_device* d, const phx_scene* s) {
+static int preprocess_impl(phx_device* d, const phx_scene* s);
+int phx_dev_preprocess(phx_device* d, const phx_scene* s) { return guarded([&]() { return preprocess_impl(d, s); }); }
+static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if (!d || !s) return fail(PHX_ERR_ARG, "preprocess: null argument");
   if (d->running) return fail(PHX_ERR_STATE, "preprocess while a frame is running");
   if (!s->meshes || !s->materials || s->num_materials == 0) return fail(PHX_ERR_ARG, "scene without meshes/materials");
@@ -352,8 +366,12 @@ int phx_dev_start(phx_device* d, const phx_frame* f) {
   d->frame = *f;
   d->running = true;
   d->frame_status = PHX_OK;
-  d->driver = std::thread([d]() { d->frame_status = d->run_frame(); });
-  return PHX_OK;
+  const int rc = guarded([&]() {
+    d->driver = std::thread([d]() { d->frame_status = guarded([d]() { return d->run_frame(); }); });
+    return (int)PHX_OK;
+  });
+  if (rc != PHX_OK) d->running = false;  // the driver thread could not be created
+  return rc;
 }
 
 int phx_dev_join(phx_device* d) {
@@ -390,7 +408,9 @@ phx_tiles* phx_tiles_make(uint32_t width, uint32_t height, uint32_t ts, uint32_t
   const uint32_t rh = height - ts * vt, rw = width - ts * ht;
   if (rh > 0) vt++;
   if (rw > 0) ht++;
-  phx_tiles* q = new phx_tiles();
+  phx_tiles* q = new (std::nothrow) phx_tiles();
+  if (!q) { fail(PHX_ERR_OOM, "host memory allocation failed"); return nullptr; }
+  try {
   // owner of tile (x, y) = (x + s*y) mod world, s the smallest odd number >= 3 coprime to world: every rank's tiles run in
   // diagonals over the whole film.  (Plain "tile id mod world" degenerates into vertical stripes whenever the row length is
   // a multiple of world — 40 tiles per row at 1280 px — and the stripes under the light cost 8 % more rays than the mean.)
@@ -403,6 +423,7 @@ phx_tiles* phx_tiles_make(uint32_t width, uint32_t height, uint32_t ts, uint32_t
       if (x == ht - 1 && rw > 0) tw = rw;
       if ((x + s * y) % world == rank) q->tiles.push_back(phx_tile{x * ts, y * ts, tw, th});
     }
+  } catch (...) { delete q; fail(PHX_ERR_OOM, "host memory allocation failed"); return nullptr; }
   return q;
 }
 int phx_tiles_next(void* tiles, phx_tile* out) {
@@ -416,7 +437,11 @@ void phx_tiles_reset(phx_tiles* q) { if (q) q->cursor = 0; }
 void phx_tiles_free(phx_tiles* q) { delete q; }
 
 // ---- stage-level entry points ----------------------------------------------------------------------------
+static int dev_trace_impl(phx_device* d, uint32_t n, const float* o, const float* dir, const float* tmax, int shadow,
+                  float* t, float* u, float* v, uint32_t* prim, uint8_t* hit);
 int phx_dev_trace(phx_device* d, uint32_t n, const float* o, const float* dir, const float* tmax, int shadow,
+                  float* t, float* u, float* v, uint32_t* prim, uint8_t* hit) { return guarded([&]() { return dev_trace_impl(d, n, o, dir, tmax, shadow, t, u, v, prim, hit); }); }
+static int dev_trace_impl(phx_device* d, uint32_t n, const float* o, const float* dir, const float* tmax, int shadow,
                   float* t, float* u, float* v, uint32_t* prim, uint8_t* hit) {
   if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "trace before preprocess");
   if (n == 0) return PHX_OK;
@@ -457,7 +482,9 @@ static int kat_upload(const float* src, size_t n, DevBuf<float>& dst) {
   return PHX_OK;
 }
 
-int phx_dev_bsdf_f(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
+static int dev_bsdf_f_impl(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3);
+int phx_dev_bsdf_f(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) { return guarded([&]() { return dev_bsdf_f_impl(d, material, n, n3, wi3, wo3, f3); }); }
+static int dev_bsdf_f_impl(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
   if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "bsdf_f before preprocess");
   if (material >= d->num_materials) return fail(PHX_ERR_ARG, "material out of range");
   if (n == 0) return PHX_OK;
@@ -471,7 +498,11 @@ int phx_dev_bsdf_f(phx_device* d, uint32_t material, uint32_t n, const float* n3
   return PHX_OK;
 }
 
+static int dev_bsdf_sample_impl(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* u2,
+                        float* wo3, float* f3, float* pdf, uint32_t* flags);
 int phx_dev_bsdf_sample(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* u2,
+                        float* wo3, float* f3, float* pdf, uint32_t* flags) { return guarded([&]() { return dev_bsdf_sample_impl(d, material, n, n3, wi3, u2, wo3, f3, pdf, flags); }); }
+static int dev_bsdf_sample_impl(phx_device* d, uint32_t material, uint32_t n, const float* n3, const float* wi3, const float* u2,
                         float* wo3, float* f3, float* pdf, uint32_t* flags) {
   if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "bsdf_sample before preprocess");
   if (material >= d->num_materials) return fail(PHX_ERR_ARG, "material out of range");
