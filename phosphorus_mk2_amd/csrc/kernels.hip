@@ -589,7 +589,7 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   static const int dyn = getenv("PHX_TRACE_DYN") ? atoi(getenv("PHX_TRACE_DYN")) : 1;
   static const int dyn_grid = getenv("PHX_TRACE_DYN_GRID") ? atoi(getenv("PHX_TRACE_DYN_GRID")) : 1;
   // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
-  static const uint32_t block = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : (dyn ? 1024u : 256u);
+  static const uint32_t block_env = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 0u;
   static const uint32_t ntop_env = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 0u;
   static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
   // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
@@ -598,14 +598,28 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   const uint32_t levels = std::max(2u, sc.stack_levels);
   // nodelets staged in LDS: whatever the per-lane stacks leave of the workgroup's share of the CU's 160 KB at full occupancy
   // (32 waves per CU); 9 (root + one level) when the stacks alone do not fit, and occupancy then follows from the LDS
-  uint32_t ntop_req = ntop_env;
-  if (!ntop_req) {
-    const uint32_t share = 160u * 1024u / (2048u / block), stacks = levels * block * 8u + 16u;
-    ntop_req = share > stacks + 9u * 80u ? (share - stacks) / 80u : 9u;
+  auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
+    uint32_t ntop_req = ntop_env;
+    if (!ntop_req) {
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = levels * blk * 8u + 16u;
+      ntop_req = share > stacks + 9u * 80u ? (share - stacks) / 80u : 9u;
+    }
+    ntop_out = std::min(ntop_req, sc.num_nodes);
+    lds_out = ntop_out * 80u + levels * blk * 8u + 16u;
+    return std::min(160u * 1024u / lds_out, 2048u / blk);
+  };
+  // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
+  // exceed the CU's LDS at full occupancy) is better served by smaller workgroups, whose LDS granularity wastes less
+  uint32_t block = block_env ? block_env : (dyn ? 1024u : 256u), ntop = 0, lds = 0, wg_per_cu = 0;
+  if (block_env || !dyn) wg_per_cu = plan(block, ntop, lds);
+  else {
+    uint32_t best_waves = 0;
+    for (uint32_t blk = 1024u; blk >= 256u; blk >>= 1) {
+      uint32_t nt, l; const uint32_t wgs = plan(blk, nt, l);
+      if (wgs * (blk / 64u) > best_waves) { best_waves = wgs * (blk / 64u); block = blk; ntop = nt; lds = l; wg_per_cu = wgs; }
+    }
   }
-  const uint32_t ntop = std::min(ntop_req, sc.num_nodes);
-  const uint32_t lds = ntop * 80u + levels * block * 8u + 16u;
-  const uint32_t wg_per_cu = std::max(1u, std::min({160u * 1024u / lds, 2048u / block, 512u * 64u * 4u / (64u * block)}));
+  if (wg_per_cu == 0) { wg_per_cu = 1; }  // deeper than the LDS can hold even with 256 threads: the launch will report the error
   const int interleave = camera_rays ? inter0 : 0;
   const uint32_t mul = (uint32_t)std::max(1, dyn ? dyn_grid : (camera_rays ? gmul0 : gmul));
   uint32_t grid = sc.num_cus * wg_per_cu * mul;
