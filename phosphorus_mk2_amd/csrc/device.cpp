@@ -319,6 +319,9 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     return fail(PHX_ERR_ARG, "unknown bvh_builder");
   }
   const auto t_bvh1 = std::chrono::steady_clock::now();
+  // k_trace keeps one pending sibling group per level and lane in LDS: 256 lanes x 8 B x depth must fit the CU's 160 KB
+  if ((size_t)bvh_depth * 256u * 8u + 16u + 9u * 80u > 160u * 1024u)
+    return fail(PHX_ERR_ARG, "BVH of depth " + std::to_string(bvh_depth) + " is deeper than the traversal stack in LDS can hold (79 levels)");
   if ((rc = d->d_prim_normals.upload(prim_normals))) return rc;
   if ((rc = d->d_materials.upload(mats))) return rc;
   if ((rc = d->d_lights.upload(lights))) return rc;
