@@ -594,8 +594,9 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
   // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
   static const uint32_t target_chunks = getenv("PHX_TARGET_CHUNKS") ? (uint32_t)atoi(getenv("PHX_TARGET_CHUNKS")) : (getenv("PHX_TRACE_DYN") && atoi(getenv("PHX_TRACE_DYN")) == 0 ? 32u : 4u);
-  // stack entries needed = BVH depth - 1 (one pending sibling group per level)
-  const uint32_t levels = std::max(2u, sc.stack_levels);
+  // stack entries needed = BVH depth - 1: one pending sibling group per level above the deepest node (the root "group" has a
+  // single member and the deepest nodes have no inner children); tests/test_host_bvh8.py checks the bound
+  const uint32_t levels = std::max(2u, sc.stack_levels > 1u ? sc.stack_levels - 1u : 1u);
   // nodelets staged in LDS: whatever the per-lane stacks leave of the workgroup's share of the CU's 160 KB at full occupancy
   // (32 waves per CU); 9 (root + one level) when the stacks alone do not fit, and occupancy then follows from the LDS
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
