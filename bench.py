@@ -94,9 +94,10 @@ def committed_traffic(args):
     (profiles/r*_100k_pmc.json, written by scripts/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE
     rocprofv3 passes).  bench.py cannot collect PMCs itself; a different workload reports null."""
     import glob
-    if (args.triangles, args.width, args.height, args.depth) != (100000, 1280, 720, 9):
+    tag = {100000: "100k", 1000000: "1M"}.get(args.triangles)
+    if tag is None or (args.width, args.height, args.depth) != (1280, 720, 9):
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_100k_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))

@@ -3,11 +3,12 @@
 # run with at most two counters of one hardware block (more fail with "exceeds the capabilities of the hardware"),
 # under its own timeout (rocprofv3 can hang after such a failure).
 TAG=${1:-x}
+BENCH_ARGS=${BENCH_ARGS:-}   # e.g. BENCH_ARGS='--triangles 1000000' for the 1 M-triangle soup
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/mem_$TAG
 mkdir -p $OUT
-run() { name=$1; shift; timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$name.log 2>&1; echo "$name rc=$?" | tee -a $OUT/progress.log; }
+run() { name=$1; shift; timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?" | tee -a $OUT/progress.log; }
 run ta1 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
 run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
