@@ -1,13 +1,15 @@
 // kernels.hip — hand-written gfx950 kernels of the wavefront path tracer (see kernels.h for the
-// HBM layout).  One ray / path per lane, 64-lane wavefronts, 256-thread workgroups.
+// HBM layout).  One ray / path per lane, 64-lane wavefronts.
 //
-//   k_generate  camera::perspective_kernel_t (reference src/kernels/cpu/camera.hpp:80-159) + spt::state_t::reset
+//   camera_ray  camera::perspective_kernel_t (reference src/kernels/cpu/camera.hpp:80-159) + spt::state_t::reset: a device
+//               function — primary rays are rebuilt on the fly by the first k_trace / k_shade of a pass, never stored
 //   k_trace     stream_mbvh_kernel_t::trace (src/kernels/cpu/stream_bvh_kernel.cpp:18-161) re-thought per lane:
-//               BVH8 nodelets, (base,mask) group stack in LDS, closest-hit and any-hit variants
+//               BVH8 nodelets, (base,mask) group stack in LDS, closest-hit and any-hit rays in one persistent launch,
+//               lanes refilled from chunks each wave pulls for itself
 //   k_shade     deferred_shading_kernel_t (deferred_shading_kernel.hpp:20-72) + light_sampler_t (spt.hpp:95-149)
 //               + integrator_t (spt.hpp:161-328) fused; survivors and shadow rays are appended to their
-//               queues with __ballot/__popcll wave compaction (one atomic per wave)
-//   k_film      the per-sample film add of tile_renderer_t::render_tile (src/xpu/cpu.cpp:175-198)
+//               queues with __ballot/__popcll compaction (one global atomic per 512-thread workgroup)
+//   k_film      the per-sample film add of tile_renderer_t::render_tile (src/xpu/cpu.cpp:175-198), in sample order
 #include "kernels.h"
 
 #include <algorithm>
