@@ -4,7 +4,6 @@ inputs of SURVEY §8(d): the Cornell box (C1) and Soup(N, seed) triangle soups (
 
 A `SceneDesc` owns numpy arrays; `pack()` builds the ctypes `phx_scene` that points into them.
 """
-import ctypes as C
 import math
 from dataclasses import dataclass, field
 from typing import List, Tuple

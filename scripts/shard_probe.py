@@ -2,7 +2,7 @@
 the frame time goes (kernel time by HIP events vs host wall time of start..join)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+
 from phosphorus_mk2_amd import scenes, xpu
 
 xpu.load_library()
