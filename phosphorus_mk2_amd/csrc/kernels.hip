@@ -109,7 +109,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
                                              const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0,
                                              const DynQueue dq) {
   const uint32_t lane = __lane_id();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   bool active = false, any = false;
   uint32_t phase = 0;  // wave-uniform: 0 = shadow range, 1 = closest range, 2 = drained
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
@@ -151,7 +150,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         base = __shfl(base, (int)leader);
       }
       if (!active) {
-        const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
+        // rank of this idle lane in pair-major order (0, 32, 1, 33, ...): consecutive rays go to the two lanes of a pair
+        const uint32_t l5 = lane & 31u, below = (1u << l5) - 1u, ilo = (uint32_t)idle, ihi = (uint32_t)(idle >> 32);
+        const uint32_t my = base + (uint32_t)__popc(ilo & below) + (uint32_t)__popc(ihi & below) + (lane >= 32u ? ((ilo >> l5) & 1u) : 0u);
         if (my < hi) {
           if (GEN && phase == 1u) {
             v3 co, cd;
