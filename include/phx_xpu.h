@@ -182,7 +182,13 @@ typedef struct phx_stats {
   uint64_t triangles;
   double   preprocess_ms;    /* wall time of the last phx_dev_preprocess */
   double   bvh_build_ms;     /* of which: tree construction (host SAH, or device LBVH incl. its upload of the triangles) */
-  uint64_t reserved[6];
+  /* the k_trace launch plan of the preprocessed scene (kernels.hip: trace_plan) */
+  uint64_t trace_block;      /* threads per k_trace workgroup: 256, 512 or 1024 */
+  uint64_t trace_ntop;       /* top-of-tree elements staged in LDS by every workgroup */
+  uint64_t trace_levels;     /* per-lane stack entries in LDS (= tree depth - 1, at least 2) */
+  uint64_t trace_waves_per_cu; /* resident k_trace waves per compute unit with that LDS footprint */
+  uint64_t bvh_depth;        /* levels of the 8-wide tree (<= 64) */
+  uint64_t paths_in_flight;  /* paths carried per wavefront pass in the last frame (pixels of a batch x samples) */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */
@@ -201,6 +207,7 @@ int         phx_dev_join(phx_device* dev);
 /* ~xpu_t */
 void        phx_dev_destroy(phx_device* dev);
 
+/* last error message of the calling thread (a frame's error is handed to the thread that calls phx_dev_join) */
 const char* phx_last_error(void);
 int         phx_dev_get_stats(const phx_device* dev, phx_stats* out);
 

@@ -59,6 +59,7 @@ def load(libm=False):
     lib.orc_destroy.argtypes = [vp]; lib.orc_destroy.restype = None
     lib.orc_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64)] + [C.POINTER(C.c_uint64)] * 2; lib.orc_bvh_info.restype = C.c_int
     lib.orc_render.argtypes = [vp, C.POINTER(RenderArgs), f32p, f32p, C.POINTER(OStats)]; lib.orc_render.restype = C.c_int
+    lib.orc_bench.argtypes = [vp, C.POINTER(RenderArgs), C.c_double, f32p, C.POINTER(OStats), u32p]; lib.orc_bench.restype = C.c_int
     lib.orc_jitter_table.argtypes = [C.c_uint64, C.c_uint32, f32p]; lib.orc_jitter_table.restype = C.c_int
     lib.orc_trace.argtypes = [vp, C.c_uint32, f32p, f32p, f32p, u32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, u32p, u32p,
                               C.POINTER(C.c_uint64)]
@@ -74,6 +75,7 @@ def load(libm=False):
     lib.orc_mt19937_head.argtypes = [C.c_uint32, f32p]
     lib.orc_counter_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
     lib.orc_light_sample.argtypes = [vp, C.c_uint32, f32p, f32p, f32p, f32p, f32p, u32p, u32p]; lib.orc_light_sample.restype = C.c_int
+    lib.orc_probe_soup.argtypes = [C.c_uint32, f32p]; lib.orc_probe_soup.restype = C.c_int
     lib.orc_bvh_dump.argtypes = [vp, f32p, u32p, u32p, u32p, u32p, u32p]; lib.orc_bvh_dump.restype = C.c_int
     _libs[name] = lib
     return lib
@@ -106,6 +108,14 @@ def set_tie_rule(lowest_prim):
     """0 (default, the reference): of two triangles hit at bitwise the same distance the one the traversal meets first wins;
     1: the one with the lower primitive index wins — the device's rule (bvh8.h).  Applies to tracers created afterwards."""
     load().orc_set_tie_rule(1 if lowest_prim else 0)
+
+
+def probe_soup(n):
+    """(n, 9) float32 triangles of the soup the survey's probe rendered with the real reference:
+    std::mt19937(1234) + std::uniform_real_distribution<float>(-1, 1), 12 draws per triangle."""
+    abc = np.zeros((n, 9), np.float32)
+    load().orc_probe_soup(n, _fp(abc))
+    return abc
 
 
 class Oracle:
@@ -153,6 +163,24 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"orc_render failed: {rc}")
         return (film, st.as_dict(), nrm) if normals else (film, st.as_dict())
+
+    def bench(self, threads, min_seconds, seed=1, tiles=None, sample_begin=0, sample_end=0):
+        """CPU-baseline timing: a warm pool of `threads` workers renders the tile list round after round (counter RNG) for at
+        least `min_seconds`; thread start-up and per-thread stream construction are outside the clock.  -> stats dict."""
+        film = np.zeros((self.H, self.W, 4), np.float32)
+        args = RenderArgs()
+        args.rng_mode, args.num_threads, args.seed = RNG_COUNTER, threads, seed
+        args.sample_begin, args.sample_end = sample_begin, sample_end
+        keep = None
+        if tiles is not None:
+            keep = (abi.Tile * len(tiles))(*[abi.Tile(*t) for t in tiles])
+            args.num_tiles, args.tiles = len(tiles), keep
+        st = OStats(); rounds = C.c_uint32(0)
+        rc = self.lib.orc_bench(self.h, C.byref(args), float(min_seconds), _fp(film), C.byref(st), C.byref(rounds))
+        if rc != 0:
+            raise RuntimeError(f"orc_bench failed: {rc}")
+        d = st.as_dict(); d["rounds"] = rounds.value
+        return d
 
     def trace(self, o, d, tmax, shadow=False, brute=False, slab_literal=0, rcp_approx=0):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)

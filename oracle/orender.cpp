@@ -28,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <random>
 #include <thread>
 
 using namespace orc;
@@ -521,6 +522,53 @@ int orc_render(void* h, const render_args_t* args, float* film, float* normals, 
   return 0;
 }
 
+// CPU-baseline timing (bench.py's cpu_baseline leg): the reference's threading unit — worker threads pulling tiles from one
+// atomic cursor (src/xpu/cpu.cpp:223-238, jobs/tiles.hpp:40-47) — with the pool WARM: every worker constructs its
+// tile_renderer_t (streams, interaction records, tracer) first, all meet at a barrier, and only then the clock starts.  The
+// tile list is rendered again and again (counter RNG: identical work each round) until `min_seconds` have passed; a worker
+// finishes the tile it is on.  stats: rays / visits of everything rendered, seconds = clock start -> last worker done.
+int orc_bench(void* h, const render_args_t* args, double min_seconds, float* film, stats_t* stats, uint32_t* rounds_out) {
+  oracle_t* o = (oracle_t*)h;
+  if (!o || !args || !film || args->rng_mode != 1) return 1;
+  if (o->scene.lights.empty()) return 2;
+  const uint32_t W = o->scene.camera.film_width, H = o->scene.camera.film_height;
+  std::vector<phx_tile> tiles = args->num_tiles ? std::vector<phx_tile>(args->tiles, args->tiles + args->num_tiles) : make_tiles(W, H, 32);
+  for (auto& t : tiles) if (t.w * t.h > STREAM || t.w % 8 != 0) return 4;
+  jitter_t J; sampler_preprocess_counter(args->seed, o->opt.samples_per_pixel, J);
+  const int nt = args->num_threads > 0 ? args->num_threads : 1;
+  std::atomic<uint64_t> cursor{0};
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false}, stop{false};
+  std::vector<stats_t> per(nt);
+  std::vector<std::thread> th;
+  std::chrono::steady_clock::time_point t0;
+  for (int k = 0; k < nt; ++k)
+    th.emplace_back([&, k]() {
+      tile_renderer_t R(*o, *args, nullptr, J);
+      R.rays.resize(STREAM); R.primary.resize(STREAM); R.hits.resize(STREAM);  // touch the streams before the clock starts
+      ready.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      for (;;) {
+        if (stop.load(std::memory_order_relaxed)) break;
+        const uint64_t t = cursor++;
+        R.render_tile(tiles[t % tiles.size()], film, nullptr);
+        if (k == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= min_seconds) stop.store(true);
+      }
+      per[k] = R.S;
+    });
+  while (ready.load() < nt) std::this_thread::yield();
+  t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
+  for (auto& t : th) t.join();
+  stats_t total{};
+  total.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (auto& p : per) add_stats(total, p);
+  total.bvh_nodes = o->bvh.nodes.size(); total.bvh_packets = o->bvh.packets.size();
+  if (stats) *stats = total;
+  if (rounds_out) *rounds_out = (uint32_t)(cursor.load() / tiles.size());
+  return 0;
+}
+
 // per-spp film jitter table of the counter sampler (spp entries, x then y)
 int orc_jitter_table(uint64_t seed, uint32_t spp, float* out_xy) {
   jitter_t J; sampler_preprocess_counter(seed, spp, J);
@@ -535,24 +583,45 @@ int orc_trace(void* h, uint32_t n, const float* o3, const float* d3, const float
               uint64_t* counters /* rays, node_visits, packet_visits */) {
   oracle_t* o = (oracle_t*)h;
   modes_t md; md.slab_literal = slab_literal; md.rcp_approx = rcp_apx;
-  stream_tracer_t tr(&o->bvh, md);
-  rays_t R;
-  for (uint32_t base = 0; base < n; base += STREAM) {
-    const uint32_t cnt = std::min(STREAM, n - base);
-    R = rays_t(); R.resize(cnt);
-    for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t g = base + i;
-      R.px[i] = o3[3 * g]; R.py[i] = o3[3 * g + 1]; R.pz[i] = o3[3 * g + 2];
-      R.wx[i] = d3[3 * g]; R.wy[i] = d3[3 * g + 1]; R.wz[i] = d3[3 * g + 2];
-      R.d[i] = tmax[g]; R.flags[i] = flags_in ? flags_in[g] : 0;
+  // 1024-slot streams are independent of each other, so they are spread over the host threads (each with its own tracer);
+  // results and counters do not depend on the thread count
+  const uint32_t kStream = ::STREAM, STREAM = mode == 0 ? kStream : 8u;  // brute force is per ray: small chunks so that a few hundred rays use every core
+  const uint32_t nstreams = (n + STREAM - 1) / STREAM;
+  const uint32_t nt = std::max(1u, std::min({nstreams, std::thread::hardware_concurrency(), 64u}));
+  std::atomic<uint32_t> cursor{0};
+  std::vector<trace_counters_t> ctrs(nt);
+  auto work = [&](uint32_t k) {
+    stream_tracer_t tr(&o->bvh, md);
+    rays_t R;
+    for (;;) {
+      const uint32_t sidx = cursor++;
+      if (sidx >= nstreams) break;
+      const uint32_t base = sidx * STREAM, cnt = std::min(STREAM, n - base);
+      R = rays_t(); R.resize(cnt);
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t g = base + i;
+        R.px[i] = o3[3 * g]; R.py[i] = o3[3 * g + 1]; R.pz[i] = o3[3 * g + 2];
+        R.wx[i] = d3[3 * g]; R.wy[i] = d3[3 * g + 1]; R.wz[i] = d3[3 * g + 2];
+        R.d[i] = tmax[g]; R.flags[i] = flags_in ? flags_in[g] : 0;
+      }
+      if (mode == 0) tr.trace(R, cnt); else trace_brute(o->bvh, R, cnt, md.tie_lowest_prim != 0);
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t g = base + i;
+        t[g] = R.d[i]; u[g] = R.u[i]; v[g] = R.v[i]; prim[g] = R.prim[i]; flags_out[g] = R.flags[i];
+      }
     }
-    if (mode == 0) tr.trace(R, cnt); else trace_brute(o->bvh, R, cnt, md.tie_lowest_prim != 0);
-    for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t g = base + i;
-      t[g] = R.d[i]; u[g] = R.u[i]; v[g] = R.v[i]; prim[g] = R.prim[i]; flags_out[g] = R.flags[i];
-    }
+    ctrs[k] = tr.ctr;
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < nt; ++k) th.emplace_back(work, k);
+    for (auto& x : th) x.join();
   }
-  if (counters) { counters[0] = tr.ctr.rays; counters[1] = tr.ctr.node_visits; counters[2] = tr.ctr.packet_visits; }
+  if (counters) {
+    counters[0] = counters[1] = counters[2] = 0;
+    for (auto& c : ctrs) { counters[0] += c.rays; counters[1] += c.node_visits; counters[2] += c.packet_visits; }
+  }
   return 0;
 }
 
@@ -609,6 +678,33 @@ void orc_simd_cmp(uint32_t n, int op, const float* l, const float* r, uint32_t* 
     out_bits[i] = m ? 0xffffffffu : 0u;
   }
 }
+// simd::int32_t<8> (src/math/simd/int8.hpp) on one lane: the compares are float instructions on the integer's
+// bits (SURVEY A-20) — +0 == -0, NaN patterns equal nothing, small non-negative integers (denormals) behave like integers as long
+// as denormals are not flushed; +, &, |, ^ are bitwise/integer.  op: 0 + | 1 identity | 2 == | 3 <= | 4 >= | 5 & | 6 "|" | 7 ^
+// (operator- is left out: simd::sub(__m256i, __m256i), int8.hpp:38-40, calls itself — undefined behaviour, unused on the hot path)
+void orc_int8_op(uint32_t n, int op, const int32_t* l, const int32_t* r, int32_t* out) {
+  auto f = [](int32_t x) { float y; std::memcpy(&y, &x, 4); return y; };
+  for (uint32_t i = 0; i < n; ++i) {
+    switch (op) {
+      case 0: out[i] = (int32_t)((uint32_t)l[i] + (uint32_t)r[i]); break;
+      case 1: out[i] = l[i]; break;
+      case 2: out[i] = f(l[i]) == f(r[i]) ? -1 : 0; break;
+      case 3: out[i] = f(l[i]) <= f(r[i]) ? -1 : 0; break;
+      case 4: out[i] = f(l[i]) >= f(r[i]) ? -1 : 0; break;
+      case 5: out[i] = l[i] & r[i]; break;
+      case 6: out[i] = l[i] | r[i]; break;
+      default: out[i] = l[i] ^ r[i]; break;
+    }
+  }
+}
+// the flag tests as THIS restatement writes them — plain integer expressions (rays_t::is_hit etc., obvh.h) — for the check
+// that on the domain of flag words they equal the reference's float-compare form
+void orc_flag_test(uint32_t n, const uint32_t* flags, uint32_t bit, int32_t* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = ((flags[i] & bit) == bit) ? -1 : 0;
+}
+void orc_int_from_float(uint32_t n, const float* x, int32_t* out) {  // _mm256_cvtps_epi32: current rounding mode = nearest even
+  for (uint32_t i = 0; i < n; ++i) out[i] = (int32_t)std::nearbyintf(x[i]);
+}
 uint64_t orc_bscf(uint64_t v, uint64_t* rest) { uint64_t x = v; uint64_t i = bscf(x); *rest = x; return i; }
 void orc_radians(uint32_t n, const float* a, float* out) { for (uint32_t i = 0; i < n; ++i) out[i] = (float)((double)a[i] * (kPi / (double)180.0f)); }
 void orc_mt19937_head(uint32_t n, float* out) { seq_rng_t r; for (uint32_t i = 0; i < n; ++i) out[i] = r.sample(); }
@@ -626,6 +722,23 @@ int orc_light_sample(void* h, uint32_t n, const float* pick, const float* u2, fl
     light_sample_t s; o->scene.lights[l].sample(V2(u2[2 * i], u2[2 * i + 1]), s);
     p3[3 * i] = s.p.x; p3[3 * i + 1] = s.p.y; p3[3 * i + 2] = s.p.z; uv2[2 * i] = s.uv.x; uv2[2 * i + 1] = s.uv.y;
     pdf[i] = s.pdf / nl; mesh[i] = s.mesh; face[i] = s.face;
+  }
+  return 0;
+}
+// The soup generator of the survey's probe: std::mt19937(1234) + std::uniform_real_distribution<float>(-1,1)
+// (libstdc++'s mapping, SURVEY A-5), 12 draws per triangle in the order centre xyz, a xyz, b xyz, c xyz; centre scaled by
+// 0.98 and shifted to z = -2.5, vertex = centre + e * U, e = 2 * n^(-1/3).  Used to replay the survey's recorded runs of
+// the real reference (tests/test_oracle_pins.py); the product's own Soup(N) uses a counter generator (scenes.py).
+int orc_probe_soup(uint32_t n, float* abc9) {
+  std::mt19937 gen(1234);
+  std::uniform_real_distribution<float> U(-1.0f, 1.0f);
+  const float e = 2.0f * std::pow((float)n, -1.0f / 3.0f);
+  for (uint32_t i = 0; i < n; ++i) {
+    float c[3];
+    for (int k = 0; k < 3; ++k) c[k] = U(gen) * 0.98f;
+    c[2] -= 2.5f;
+    for (int v = 0; v < 3; ++v)
+      for (int k = 0; k < 3; ++k) abc9[9 * (size_t)i + 3 * v + k] = c[k] + e * U(gen);
   }
   return 0;
 }

@@ -90,7 +90,9 @@ class Stats(C.Structure):
         ("rays_masked", C.c_uint64), ("tiles", C.c_uint64), ("trace_launches", C.c_uint64),
         ("trace_ms", C.c_double), ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
         ("frame_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64), ("triangles", C.c_uint64),
-        ("preprocess_ms", C.c_double), ("bvh_build_ms", C.c_double), ("reserved", C.c_uint64 * 6),
+        ("preprocess_ms", C.c_double), ("bvh_build_ms", C.c_double),
+        ("trace_block", C.c_uint64), ("trace_ntop", C.c_uint64), ("trace_levels", C.c_uint64), ("trace_waves_per_cu", C.c_uint64),
+        ("bvh_depth", C.c_uint64), ("paths_in_flight", C.c_uint64),
     ]
 
 

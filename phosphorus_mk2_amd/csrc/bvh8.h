@@ -38,6 +38,11 @@ struct TriRec {  // 48 B: three 16-byte words
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be three 16-byte words");
 
+// One depth limit for every consumer of the tree: the builders refuse deeper trees, k_trace / k_trace_rays size their per-lane
+// LDS stacks from the depth (<= 64 levels x 256 lanes x 8 B = 128 KB of the CU's 160 KB).
+#define PHX_MAX_BVH_DEPTH 64
+#define PHX_NODE_LDS_BYTES 80u  /* bytes a staged nodelet occupies in LDS */
+
 struct Hit { float t, u, v; uint32_t tri; };  // tri = index of the TriRec, 0xffffffff = miss
 
 PHX_HD int clz32(uint32_t x) {

@@ -266,7 +266,13 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restric
 int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen) {
   out->nodes = nullptr; out->tris = nullptr; out->num_nodes = 0; out->num_tris = 0; out->depth = 1;
   void* bufs[16]; int nb = 0;
-  auto cleanup = [&]() { for (int i = 0; i < nb; ++i) (void)hipFree(bufs[i]); };
+  Node8* nodes = nullptr; TriRec* tris = nullptr;  // the outputs: freed by cleanup() unless the build succeeds
+  bool keep_outputs = false;
+  auto cleanup = [&]() {
+    for (int i = 0; i < nb; ++i) (void)hipFree(bufs[i]);
+    nb = 0;
+    if (!keep_outputs) { if (nodes) (void)hipFree(nodes); if (tris) (void)hipFree(tris); nodes = nullptr; tris = nullptr; }
+  };
   auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; bufs[nb++] = p; return p; };
   if (n < 2) { std::snprintf(err, errlen, "device builder needs at least 2 triangles"); return 1; }
   Box6* pbox = (Box6*)dalloc(sizeof(Box6) * n);
@@ -298,9 +304,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   HCHK(hipGetLastError());
 
   // outputs: at most n-1 inner BVH2 nodes can become Node8s (+1), exactly n triangle records
-  Node8* nodes = nullptr; TriRec* tris = nullptr;
   if (hipMalloc((void**)&nodes, sizeof(Node8) * (size_t)n) != hipSuccess || hipMalloc((void**)&tris, sizeof(TriRec) * (size_t)n) != hipSuccess) {
-    if (nodes) (void)hipFree(nodes);
     std::snprintf(err, errlen, "hipMalloc failed (BVH8 arrays)"); cleanup(); return 1;
   }
   uint32_t* qa[2] = {queues, queues + 2 * (size_t)n}; uint32_t* qb[2] = {queues + (size_t)n, queues + 3 * (size_t)n};
@@ -323,12 +327,16 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
     const uint32_t z = 0;
     HCHK(hipMemcpyAsync(counters + 2, &z, 4, hipMemcpyHostToDevice, stream));
     cur ^= 1;
-    if (depth > 64) break;
+    if (count > 0 && depth >= PHX_MAX_BVH_DEPTH) {
+      std::snprintf(err, errlen, "tree too deep: more than %d levels (PHX_MAX_BVH_DEPTH, the traversal stack in LDS)", PHX_MAX_BVH_DEPTH);
+      cleanup(); return 1;
+    }
   }
   HCHK(hipStreamSynchronize(stream));
+  if (h_counters[1] != n) { std::snprintf(err, errlen, "device BVH builder lost triangles (%u of %u)", h_counters[1], n); cleanup(); return 1; }
+  keep_outputs = true;
   out->nodes = nodes; out->tris = tris; out->num_nodes = h_counters[0]; out->num_tris = h_counters[1]; out->depth = depth;
   cleanup();
-  if (out->num_tris != n) { std::snprintf(err, errlen, "device BVH builder lost triangles (%u of %u)", out->num_tris, n); (void)hipFree(nodes); (void)hipFree(tris); out->nodes = nullptr; out->tris = nullptr; return 1; }
   return 0;
 }
 

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -24,10 +25,11 @@ using namespace phx;
 
 namespace {
 
+// Errors: every thread has its own last-error string; a driver thread's error is also kept with its device (phx_device::
+// frame_error) and handed to the thread that calls phx_dev_join, so two devices rendering at once never share a buffer.
 thread_local std::string g_error;
-std::string g_error_shared;  // last error of any driver thread (read by phx_last_error after join)
 
-int fail(int code, const std::string& msg) { g_error = msg; g_error_shared = msg; return code; }
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
 
 #define HIPCHK(expr)                                                                                     \
   do {                                                                                                   \
@@ -88,7 +90,10 @@ struct phx_device {
   std::thread driver;
   bool running = false;
   int frame_status = PHX_OK;
+  std::string frame_error;  // g_error of the driver thread, copied before it exits
   phx_stats stats{};
+  TracePlan plan{};
+  uint64_t paths_in_flight = 0;
   std::vector<hipEvent_t> events; size_t events_used = 0;
   std::vector<std::pair<size_t, int>> timed;  // (event index of start, kind 0 closest / 1 shadow / 2 other)
 
@@ -174,7 +179,7 @@ int guarded(F&& body) {
 
 extern "C" {
 
-const char* phx_last_error(void) { return g_error.empty() ? g_error_shared.c_str() : g_error.c_str(); }
+const char* phx_last_error(void) { return g_error.c_str(); }  // last error of the CALLING thread
 
 int phx_discover(const phx_options* options, int* num_devices) {
   if (!num_devices) return fail(PHX_ERR_ARG, "phx_discover: null out pointer");
@@ -213,6 +218,9 @@ phx_device* phx_dev_make(const phx_options* options) {
   if (d->opt.paths_per_sample == 0) d->opt.paths_per_sample = 1;
   if (d->opt.path_depth == 0) d->opt.path_depth = 9;
   if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { delete d; fail(PHX_ERR_DEVICE, "hipStreamCreate failed"); return nullptr; }
+  // dynamic-LDS limit of the traversal kernels: a per-device, per-kernel attribute, so it is set for every device made
+  const hipError_t ae = init_kernels_on_current_device();
+  if (ae != hipSuccess) { delete d; fail(PHX_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ae)); return nullptr; }
   return d;
 }
 
@@ -319,9 +327,9 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     return fail(PHX_ERR_ARG, "unknown bvh_builder");
   }
   const auto t_bvh1 = std::chrono::steady_clock::now();
-  // k_trace keeps one pending sibling group per level and lane in LDS: 256 lanes x 8 B x depth must fit the CU's 160 KB
-  if ((size_t)bvh_depth * 256u * 8u + 16u + 9u * 80u > 160u * 1024u)
-    return fail(PHX_ERR_ARG, "BVH of depth " + std::to_string(bvh_depth) + " is deeper than the traversal stack in LDS can hold (79 levels)");
+  // k_trace / k_trace_rays keep one pending sibling group per level and lane in LDS (bvh8.h: PHX_MAX_BVH_DEPTH)
+  if (bvh_depth > PHX_MAX_BVH_DEPTH)
+    return fail(PHX_ERR_ARG, "tree too deep: " + std::to_string(bvh_depth) + " levels, the traversal stack in LDS holds " + std::to_string(PHX_MAX_BVH_DEPTH));
   if ((rc = d->d_prim_normals.upload(prim_normals))) return rc;
   if ((rc = d->d_materials.upload(mats))) return rc;
   if ((rc = d->d_lights.upload(lights))) return rc;
@@ -355,6 +363,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   d->bvh_build_ms = std::chrono::duration<double, std::milli>(t_bvh1 - t_bvh0).count();
   d->preprocess_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pre0).count();
   d->num_triangles = prim_material.size();
+  d->plan = trace_plan(sc);
   d->preprocessed = true;
   return PHX_OK;
 }
@@ -370,7 +379,10 @@ int phx_dev_start(phx_device* d, const phx_frame* f) {
   d->running = true;
   d->frame_status = PHX_OK;
   const int rc = guarded([&]() {
-    d->driver = std::thread([d]() { d->frame_status = guarded([d]() { return d->run_frame(); }); });
+    d->driver = std::thread([d]() {
+      d->frame_status = guarded([d]() { return d->run_frame(); });
+      d->frame_error = d->frame_status != PHX_OK ? g_error : std::string();
+    });
     return (int)PHX_OK;
   });
   if (rc != PHX_OK) d->running = false;  // the driver thread could not be created
@@ -382,7 +394,7 @@ int phx_dev_join(phx_device* d) {
   if (!d->running) return fail(PHX_ERR_STATE, "join without start");
   d->driver.join();
   d->running = false;
-  if (d->frame_status != PHX_OK) g_error = g_error_shared;
+  if (d->frame_status != PHX_OK) g_error = d->frame_error;
   return d->frame_status;
 }
 
@@ -391,6 +403,9 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   *out = d->stats;
   out->bvh_nodes = d->bvh_nodes; out->bvh_bytes = d->bvh_bytes; out->triangles = d->num_triangles;
   out->preprocess_ms = d->preprocess_ms; out->bvh_build_ms = d->bvh_build_ms;
+  out->trace_block = d->plan.block; out->trace_ntop = d->plan.ntop; out->trace_levels = d->plan.levels;
+  out->trace_waves_per_cu = (uint64_t)d->plan.wg_per_cu * (d->plan.block / 64u); out->bvh_depth = d->scene.stack_levels;
+  out->paths_in_flight = d->paths_in_flight;
   return PHX_OK;
 }
 
@@ -460,20 +475,12 @@ static int dev_trace_impl(phx_device* d, uint32_t n, const float* o, const float
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(d->stream));
   HIPCHK(hipMemcpy(hh.data(), c.p, n * sizeof(float4), hipMemcpyDeviceToHost));
-  std::vector<TriRec> one(1);
-  std::vector<uint32_t> tri_prim;  // triangle record -> primitive id
-  {
-    std::vector<TriRec> all(d->d_tris.n);
-    HIPCHK(hipMemcpy(all.data(), d->d_tris.p, all.size() * sizeof(TriRec), hipMemcpyDeviceToHost));
-    tri_prim.resize(all.size());
-    for (size_t i = 0; i < all.size(); ++i) tri_prim[i] = all[i].prim;
-  }
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t tri; std::memcpy(&tri, &hh[i].w, 4);
     if (t) t[i] = hh[i].x;
     if (u) u[i] = hh[i].y;
     if (v) v[i] = hh[i].z;
-    if (prim) prim[i] = tri == 0xffffffffu ? 0xffffffffu : tri_prim[tri];
+    if (prim) prim[i] = tri;  // k_trace_rays stores the primitive id (scene_t::triangles() order), 0xffffffff on a miss
     if (hit) hit[i] = tri != 0xffffffffu;
   }
   return PHX_OK;
@@ -565,7 +572,7 @@ int phx_device::run_frame() {
     uint64_t px = 0;
     phx_tile t;
     while ((opt.tiles_per_batch == 0 || tiles.size() < opt.tiles_per_batch) && px < pixel_cap && frame.next_tile(frame.tiles_user, &t)) {
-      if (t.w == 0 || t.h == 0 || t.x + t.w > scene.width || t.y + t.h > scene.height) return fail(PHX_ERR_ARG, "tile outside the film");
+      if (t.w == 0 || t.h == 0 || (uint64_t)t.x + t.w > scene.width || (uint64_t)t.y + t.h > scene.height) return fail(PHX_ERR_ARG, "tile outside the film");
       tiles.push_back(t); px += (uint64_t)t.w * t.h;
     }
     if (tiles.empty()) break;
@@ -594,20 +601,30 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   uint32_t P = 0;
   for (auto& t : tiles) P += t.w * t.h;
   const uint32_t spp = opt.samples_per_pixel;
+  const uint32_t xs = frame.primary_components + (frame.normals_channel ? 3u : 0u);
+  // bytes of queues + state per path in flight: ray queues 2 x 32, hit 16, shadow queue 48, path state 32 (+ 16 with normals)
+  const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
   uint32_t S = opt.samples_in_flight;
   if (S == 0) {
-    // paths in flight: up to 256 M (about 43 GB of queues + state: sized for 288 GB of HBM; measured +3.5 % over 128 M).  Deep bounces keep only
-    // a few percent of the paths alive, so many samples per pass are what keeps late launches full; the spp
+    // paths in flight: up to 256 M (about 43 GB of queues + state: sized for 288 GB of HBM; measured +3.5 % over 128 M), but never
+    // more than 60 % of what the device has free right now (another device object, torch or RCCL may share the GPU).  Deep
+    // bounces keep only a few percent of the paths alive, so many samples per pass are what keeps late launches full; the spp
     // range is then split into equal passes.
-    const uint64_t budget = 256ull << 20;
+    uint64_t budget = 256ull << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      size_t held = 0;  // what this device already holds for queues is reusable
+      for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n) * sizeof(float4);
+      held += (hit.n + so.n + sd.n + sc.n + pb.n + pr.n + pn.n) * sizeof(float4);
+      budget = std::min<uint64_t>(budget, (uint64_t)((double)(free_b + held) * 0.6) / path_bytes);
+    }
+    budget = std::max<uint64_t>(budget, P);
     const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / P, 0x7ffffff0ull / P));
     const uint32_t npasses = (spp + smax - 1) / smax;
     S = (spp + npasses - 1) / npasses;
   }
   S = std::min(S, spp);
-  const size_t npaths = (size_t)P * S;
-  if (npaths >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");
-  const uint32_t xs = frame.primary_components + (frame.normals_channel ? 3u : 0u);
+  if ((size_t)P * S >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");
 
   // pixel table of the batch; a frame loop presents the same tiles again and again, so the upload is skipped when nothing changed
   if (tiles.size() != pix_xy_tiles.size() || std::memcmp(tiles.data(), pix_xy_tiles.data(), tiles.size() * sizeof(phx_tile)) != 0) {
@@ -620,10 +637,23 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     if ((rc = pix_xy.upload(xy))) return rc;
     pix_xy_tiles = tiles;
   }
-  for (int q = 0; q < 2; ++q) if ((rc = ro[q].alloc(npaths)) || (rc = rd[q].alloc(npaths))) return rc;
-  if ((rc = hit.alloc(npaths)) || (rc = so.alloc(npaths)) || (rc = sd.alloc(npaths)) || (rc = sc.alloc(npaths)) ||
-      (rc = pb.alloc(npaths)) || (rc = pr.alloc(npaths)) || (rc = acc.alloc((size_t)P * xs))) return rc;
-  if (frame.normals_channel && (rc = pn.alloc(npaths))) return rc;
+  if ((rc = acc.alloc((size_t)P * xs))) return rc;
+  // queues + state; when the device cannot hold S samples per pixel in flight, back off to half as many (more, shorter passes)
+  size_t npaths = 0;
+  for (;;) {
+    npaths = (size_t)P * S;
+    rc = PHX_OK;
+    for (int q = 0; q < 2 && !rc; ++q) if ((rc = ro[q].alloc(npaths)) || (rc = rd[q].alloc(npaths))) break;
+    if (!rc) (void)((rc = hit.alloc(npaths)) || (rc = so.alloc(npaths)) || (rc = sd.alloc(npaths)) || (rc = sc.alloc(npaths)) ||
+                    (rc = pb.alloc(npaths)) || (rc = pr.alloc(npaths)) || (frame.normals_channel && (rc = pn.alloc(npaths))));
+    if (!rc) break;
+    if (rc != PHX_ERR_OOM || S == 1) return rc;
+    (void)hipGetLastError();
+    for (int q = 0; q < 2; ++q) { ro[q].release(); rd[q].release(); }
+    hit.release(); so.release(); sd.release(); sc.release(); pb.release(); pr.release(); pn.release();
+    S = (S + 1) / 2;
+  }
+  paths_in_flight = npaths;
   HIPCHK(hipMemsetAsync(acc.p, 0, (size_t)P * xs * sizeof(float), stream));
 
   PassBuffers B{};

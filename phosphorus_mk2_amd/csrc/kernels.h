@@ -64,6 +64,12 @@ struct PassBuffers {
   uint64_t seed;
 };
 
+// shape of a k_trace launch on a scene (reported through phx_stats so that tests can assert which plan a tree ran with)
+struct TracePlan { uint32_t block, ntop, levels, lds_bytes, wg_per_cu; };
+TracePlan trace_plan(const DevScene& sc);
+// per device, once: lets the traversal kernels use the CU's full 160 KB of LDS as dynamic shared memory
+hipError_t init_kernels_on_current_device();
+
 // launches (all asynchronous on `stream`)
 // start of a pass: queue 0 stands for the num_pixels x num_samples camera rays, which are rebuilt on the fly (camera_ray)
 void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples);

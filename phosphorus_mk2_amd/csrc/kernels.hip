@@ -187,7 +187,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
         uint32_t w[20];
         if (ni < ntop) {  // top-of-tree nodelet staged in LDS: five ds_read_b128 instead of five L1 requests per lane
-          const uint4* s4 = top + ni * 5u;
+          const uint4* s4 = top + ni * (PHX_NODE_LDS_BYTES / 16u);
 #pragma unroll
           for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
         } else {
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
                                                  int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t gmul, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
-  uint2* stack = reinterpret_cast<uint2*>(smem + ntop * 5u);
+  uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
   uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
   const uint32_t n_closest = do_closest ? pb.counters[q] : 0u;
   const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq] : 0u;
@@ -310,16 +310,18 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
   trace_stream<BLOCK, GEN, DYN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0, dq);
 }
 
-template <int LEVELS, bool ANY>
+// stage-level hook (phx_dev_trace): one ray per lane run to completion with the plain traverse8 loop of bvh8.h.  The per-lane
+// stack lives in dynamic LDS sized by the depth of the tree (<= PHX_MAX_BVH_DEPTH levels x 256 lanes x 8 B = 128 KB).
+template <bool ANY>
 __global__ void __launch_bounds__(PHX_BLOCK) k_trace_rays(DevScene sc, uint32_t n, const float4* ro, const float4* rd, float4* hit) {
-  __shared__ uint2 lds[LEVELS * PHX_BLOCK];
+  extern __shared__ uint2 ray_stack[];
   const uint32_t i = blockIdx.x * PHX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const float4 a = ro[i], b = rd[i];
-  LdsStack<LEVELS> st{lds + threadIdx.x, 0};
+  LdsStack<0> st{ray_stack + threadIdx.x, 0};
   Hit h;
   traverse8<ANY>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
-  hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri));
+  hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri == 0xffffffffu ? 0xffffffffu : sc.tris[h.tri].prim));  // primitive in scene_t::triangles() order
 }
 
 // ---- shade + next-event estimation + integrate ------------------------------------------------------
@@ -583,57 +585,95 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + PHX_BLOCK - 1) / PHX
 void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples) {
   hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(1), 0, stream, pb, num_samples);
 }
-void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
-                  int camera_rays, uint32_t sample0) {
-  static const int gmul = getenv("PHX_TRACE_GRID") ? atoi(getenv("PHX_TRACE_GRID")) : 4;
-  static const int gmul0 = getenv("PHX_TRACE_GRID0") ? atoi(getenv("PHX_TRACE_GRID0")) : 16;
-  static const int inter0 = getenv("PHX_TRACE_INTER0") ? atoi(getenv("PHX_TRACE_INTER0")) : 1;
-  static const uint32_t refill = getenv("PHX_REFILL") ? (uint32_t)atoi(getenv("PHX_REFILL")) : 8u;
-  static const int dyn = getenv("PHX_TRACE_DYN") ? atoi(getenv("PHX_TRACE_DYN")) : 1;
-  static const int dyn_grid = getenv("PHX_TRACE_DYN_GRID") ? atoi(getenv("PHX_TRACE_DYN_GRID")) : 1;
-  // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
-  static const uint32_t block_env = getenv("PHX_TRACE_BLOCK") ? (uint32_t)atoi(getenv("PHX_TRACE_BLOCK")) : 0u;
-  static const uint32_t ntop_env = getenv("PHX_NTOP") ? (uint32_t)atoi(getenv("PHX_NTOP")) : 0u;
-  static const uint32_t min_chunks = getenv("PHX_MIN_CHUNKS") ? (uint32_t)atoi(getenv("PHX_MIN_CHUNKS")) : 8u;
-  // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
-  static const uint32_t target_chunks = getenv("PHX_TARGET_CHUNKS") ? (uint32_t)atoi(getenv("PHX_TARGET_CHUNKS")) : (getenv("PHX_TRACE_DYN") && atoi(getenv("PHX_TRACE_DYN")) == 0 ? 32u : 4u);
+namespace {
+struct TraceEnv {
+  int gmul, gmul0, inter0, dyn, dyn_grid;
+  uint32_t refill, block_env, ntop_env, min_chunks, target_chunks;
+};
+const TraceEnv& trace_env() {
+  static const TraceEnv e = [] {
+    auto geti = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+    TraceEnv t;
+    t.gmul = geti("PHX_TRACE_GRID", 4); t.gmul0 = geti("PHX_TRACE_GRID0", 16); t.inter0 = geti("PHX_TRACE_INTER0", 1);
+    t.refill = (uint32_t)geti("PHX_REFILL", 8); t.dyn = geti("PHX_TRACE_DYN", 1); t.dyn_grid = geti("PHX_TRACE_DYN_GRID", 1);
+    // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
+    t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
+    t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
+    // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
+    t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : 4);
+    return t;
+  }();
+  return e;
+}
+template <typename F>
+void for_each_trace_kernel(F&& f) {
+  f(reinterpret_cast<const void*>(&k_trace<256, true, true>)); f(reinterpret_cast<const void*>(&k_trace<512, true, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, true, true>));
+  f(reinterpret_cast<const void*>(&k_trace<256, false, true>)); f(reinterpret_cast<const void*>(&k_trace<512, false, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true>));
+  f(reinterpret_cast<const void*>(&k_trace<256, true, false>)); f(reinterpret_cast<const void*>(&k_trace<512, true, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, true, false>));
+  f(reinterpret_cast<const void*>(&k_trace<256, false, false>)); f(reinterpret_cast<const void*>(&k_trace<512, false, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, false>));
+  f(reinterpret_cast<const void*>(&k_trace_rays<true>)); f(reinterpret_cast<const void*>(&k_trace_rays<false>));
+}
+}  // namespace
+
+// Allow every traversal kernel the CU's full 160 KB of LDS as dynamic shared memory ON THE CURRENT DEVICE.  The attribute is
+// per device and per kernel, so the host calls this once for each phx_device it makes (device.cpp: phx_dev_make).
+hipError_t init_kernels_on_current_device() {
+  hipError_t rc = hipSuccess;
+  for_each_trace_kernel([&](const void* k) {
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess && rc == hipSuccess) rc = e;
+  });
+  return rc;
+}
+
+// What a k_trace launch on this scene looks like: workgroup size, nodelets staged in LDS, stack levels, LDS bytes.
+TracePlan trace_plan(const DevScene& sc) {
+  const TraceEnv& E = trace_env();
+  TracePlan P{};
   // stack entries needed = BVH depth - 1: one pending sibling group per level above the deepest node (the root "group" has a
   // single member and the deepest nodes have no inner children); tests/test_host_bvh8.py checks the bound
-  const uint32_t levels = std::max(2u, sc.stack_levels > 1u ? sc.stack_levels - 1u : 1u);
+  P.levels = std::max(2u, sc.stack_levels > 1u ? sc.stack_levels - 1u : 1u);
   // nodelets staged in LDS: whatever the per-lane stacks leave of the workgroup's share of the CU's 160 KB at full occupancy
   // (32 waves per CU); 9 (root + one level) when the stacks alone do not fit, and occupancy then follows from the LDS
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
-    uint32_t ntop_req = ntop_env;
+    uint32_t ntop_req = E.ntop_env;
     if (!ntop_req) {
-      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = levels * blk * 8u + 16u;
-      ntop_req = share > stacks + 9u * 80u ? (share - stacks) / 80u : 9u;
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.levels * blk * 8u + 16u;
+      ntop_req = share > stacks + 9u * PHX_NODE_LDS_BYTES ? (share - stacks) / PHX_NODE_LDS_BYTES : 9u;
     }
     ntop_out = std::min(ntop_req, sc.num_nodes);
-    lds_out = ntop_out * 80u + levels * blk * 8u + 16u;
+    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.levels * blk * 8u + 16u;
     return std::min(160u * 1024u / lds_out, 2048u / blk);
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
   // exceed the CU's LDS at full occupancy) is better served by smaller workgroups, whose LDS granularity wastes less
-  uint32_t block = block_env ? block_env : (dyn ? 1024u : 256u), ntop = 0, lds = 0, wg_per_cu = 0;
-  if (block_env || !dyn) wg_per_cu = plan(block, ntop, lds);
+  P.block = E.block_env ? E.block_env : (E.dyn ? 1024u : 256u);
+  if (E.block_env || !E.dyn) P.wg_per_cu = plan(P.block, P.ntop, P.lds_bytes);
   else {
     uint32_t best_waves = 0;
     for (uint32_t blk = 1024u; blk >= 256u; blk >>= 1) {
       uint32_t nt, l; const uint32_t wgs = plan(blk, nt, l);
-      if (wgs * (blk / 64u) > best_waves) { best_waves = wgs * (blk / 64u); block = blk; ntop = nt; lds = l; wg_per_cu = wgs; }
+      if (wgs * (blk / 64u) > best_waves) { best_waves = wgs * (blk / 64u); P.block = blk; P.ntop = nt; P.lds_bytes = l; P.wg_per_cu = wgs; }
     }
   }
-  if (wg_per_cu == 0) { wg_per_cu = 1; }  // deeper than the LDS can hold even with 256 threads: the launch will report the error
-  const int interleave = camera_rays ? inter0 : 0;
-  const uint32_t mul = (uint32_t)std::max(1, dyn ? dyn_grid : (camera_rays ? gmul0 : gmul));
-  uint32_t grid = sc.num_cus * wg_per_cu * mul;
+  if (P.wg_per_cu == 0) P.wg_per_cu = 1;  // deeper than the LDS can hold even with 256 threads: the launch will report the error
+  return P;
+}
+
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
+                  int camera_rays, uint32_t sample0) {
+  const TraceEnv& E = trace_env();
+  const TracePlan P = trace_plan(sc);
+  const uint32_t block = P.block, ntop = P.ntop, lds = P.lds_bytes, levels = P.levels;
+  const int dyn = E.dyn;
+  const int interleave = camera_rays ? E.inter0 : 0;
+  const uint32_t mul = (uint32_t)std::max(1, dyn ? E.dyn_grid : (camera_rays ? E.gmul0 : E.gmul));
+  uint32_t grid = sc.num_cus * P.wg_per_cu * mul;
   const uint32_t need = (((capacity + block - 1) / block + 7u) / 8u) * 8u;
   grid = std::max(8u, std::min(grid, need));
   const dim3 g(grid), b(block);
   auto go = [&](auto kernel) {
-    static bool attr_set = false;  // one flag per instantiation: allow the full 160 KB of LDS as dynamic shared memory
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, refill, interleave, ntop, levels, min_chunks, sample0, mul, target_chunks);
+    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, interleave, ntop, levels, E.min_chunks, sample0, mul, E.target_chunks);
   };
   if (dyn) {
     if (camera_rays) { if (block == 256) go(&k_trace<256, true, true>); else if (block == 512) go(&k_trace<512, true, true>); else go(&k_trace<1024, true, true>); }
@@ -662,13 +702,9 @@ void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* devic
 }
 void launch_trace_rays(hipStream_t stream, const DevScene& sc, uint32_t n, const float4* ro, const float4* rd, float4* hit, int any) {
   const dim3 g(blocks_for(n)), b(PHX_BLOCK);
-  if (sc.stack_levels <= 24) {
-    if (any) hipLaunchKernelGGL((k_trace_rays<24, true>), g, b, 0, stream, sc, n, ro, rd, hit);
-    else hipLaunchKernelGGL((k_trace_rays<24, false>), g, b, 0, stream, sc, n, ro, rd, hit);
-  } else {
-    if (any) hipLaunchKernelGGL((k_trace_rays<64, true>), g, b, 0, stream, sc, n, ro, rd, hit);
-    else hipLaunchKernelGGL((k_trace_rays<64, false>), g, b, 0, stream, sc, n, ro, rd, hit);
-  }
+  const size_t lds = (size_t)std::max(2u, std::min(sc.stack_levels, (uint32_t)PHX_MAX_BVH_DEPTH)) * PHX_BLOCK * sizeof(uint2);
+  if (any) hipLaunchKernelGGL((k_trace_rays<true>), g, b, lds, stream, sc, n, ro, rd, hit);
+  else hipLaunchKernelGGL((k_trace_rays<false>), g, b, lds, stream, sc, n, ro, rd, hit);
 }
 void launch_bsdf_f(hipStream_t stream, const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
   hipLaunchKernelGGL(k_bsdf_f, dim3((n + 63) / 64), dim3(64), 0, stream, mat, n, n3, wi3, wo3, f3);

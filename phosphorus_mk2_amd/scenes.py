@@ -184,14 +184,17 @@ def soup(n, seed=1234, width=1280, height=720, fov=1.9, light=True, materials=No
     y=+1.5 facing down, L_e=(17,12,4)/pi, outside the cloud.
     """
     n = int(n)
-    idx = np.arange(n * 12, dtype=np.uint64)
-    u = (_u01(idx, seed) * np.float32(2.0) - np.float32(1.0)).reshape(n, 12)
     e = np.float32(2.0 * n ** (-1.0 / 3.0))
-    centre = u[:, 0:3] * np.float32(0.98)
-    centre[:, 2] -= np.float32(2.5)
     verts = np.empty((n, 3, 3), np.float32)
-    for k in range(3):
-        verts[:, k, :] = centre + e * u[:, 3 + 3 * k:6 + 3 * k]
+    step = 1 << 16  # triangles per block: the 64-bit hash temporaries of a block stay in cache (10 M triangles: 30 s -> 4 s)
+    for t0 in range(0, n, step):
+        t1 = min(n, t0 + step)
+        idx = np.arange(t0 * 12, t1 * 12, dtype=np.uint64)
+        u = (_u01(idx, seed) * np.float32(2.0) - np.float32(1.0)).reshape(t1 - t0, 12)
+        centre = u[:, 0:3] * np.float32(0.98)
+        centre[:, 2] -= np.float32(2.5)
+        for k in range(3):
+            verts[t0:t1, k, :] = centre + e * u[:, 3 + 3 * k:6 + 3 * k]
     faces = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
     mats = list(materials) if materials else [diffuse(0.73, 0.73, 0.73)]
     nm = len(mats)

@@ -1,6 +1,6 @@
 """Generates tests/golden/ref_subset_vectors.npz from oracle/_ref/libphx_ref_subset.so — object code
 compiled from the reference's own dependency-free headers (src/math/fresnel.hpp, src/math/trigonometry.hpp,
-src/math/simd/float8.hpp, src/utils/compiler.hpp) where they lie under /root/reference.  These are the only
+src/math/simd/float8.hpp, src/math/simd/int8.hpp, src/utils/compiler.hpp) where they lie under /root/reference.  These are the only
 vectors that pin the oracle to outputs of the reference itself; run here (the reference never travels):
 
     make -C oracle ref && python tests/golden/make_ref_subset_vectors.py
@@ -43,6 +43,31 @@ bs_in = rng.integers(1, 2 ** 62, 64).astype(np.uint64); bs_idx = np.zeros(64, np
 for i in range(64):
     rest = C.c_uint64()
     bs_idx[i] = lib.ref_bscf(int(bs_in[i]), C.byref(rest)); bs_rest[i] = rest.value
+# simd::int32_t<8> (src/math/simd/int8.hpp): integer ops done with float instructions on the bits (SURVEY A-20)
+i32p = C.POINTER(C.c_int32)
+ip = lambda a: a.ctypes.data_as(i32p)
+il = rng.integers(0, 16, (32, 8)).astype(np.int32); ir = rng.integers(0, 16, (32, 8)).astype(np.int32)   # the flags domain
+il[8:16] = rng.integers(-2 ** 31, 2 ** 31, (8, 8)); ir[8:16] = rng.integers(-2 ** 31, 2 ** 31, (8, 8))       # any bit pattern
+il[16:24] = rng.integers(0, 3000000, (8, 8)); ir[16:24] = rng.integers(0, 3000000, (8, 8))                # face / mesh ids
+il[24, :6] = [0, -2 ** 31, 0x7fc00000, 0x7fc00000, 1, 0x00800000]; ir[24, :6] = [-2 ** 31, 0, 0x7fc00000, 0, 1, 0x00800000]
+il[25:] = il[25:] | (rng.integers(0, 2, (7, 8)).astype(np.int32) << 16); ir[25:] = il[25:]               # equal operands
+iop = np.zeros((8, 32, 8), np.int32)
+for op in range(8):
+    for i in range(32):
+        lib.ref_int8_op(op, ip(il[i]), ip(ir[i]), ip(iop[op, i]))
+flag_words = np.arange(16, dtype=np.int32).reshape(2, 8)
+flag_out = np.zeros((4, 2, 8), np.int32)
+for k, bit in enumerate((1, 2, 4, 8)):   # HIT, MASKED, SHADOW, SPECULAR (src/state.hpp:33-36)
+    for i in range(2):
+        lib.ref_int8_flag_test(ip(flag_words[i]), bit, ip(flag_out[k, i]))
+cvt_in = rng.uniform(-1000, 1000, (16, 8)).astype(np.float32); cvt_in[0] = [0.5, 1.5, 2.5, -0.5, -1.5, 0.49999997, 1e6, -0.0]
+cvt_out = np.zeros((16, 8), np.int32)
+isel = np.zeros((32, 8), np.int32)
+for i in range(16):
+    lib.ref_int8_from_float(fp(cvt_in[i]), ip(cvt_out[i]))
+for i in range(32):
+    lib.ref_int8_select(fp(mask[i]), ip(il[i]), ip(ir[i]), ip(isel[i]))
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_subset_vectors.npz"), cosi=cosi, eta=eta, fresnel=fres, deg=deg, rad=rad,
-                    l=l, r=r, mask=mask, select=sel, cmp=cmp.view(np.uint32), minmax=mm, bscf_in=bs_in, bscf_idx=bs_idx, bscf_rest=bs_rest)
+                    l=l, r=r, mask=mask, select=sel, cmp=cmp.view(np.uint32), minmax=mm, bscf_in=bs_in, bscf_idx=bs_idx, bscf_rest=bs_rest,
+                    int_l=il, int_r=ir, int_op=iop, flag_words=flag_words, flag_test=flag_out, cvt_in=cvt_in, cvt_out=cvt_out, int_select=isel)
 print("wrote ref_subset_vectors.npz")

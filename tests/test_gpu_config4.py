@@ -1,0 +1,101 @@
+"""BASELINE config #4 through the C ABI: Soup(10 000 000), 3840x2160 — the 695 MB tree, deeper stack, another k_trace
+launch plan, 32-bit index arithmetic at 10 M triangles — against the CPU oracle (reference-layout BVH built by the restated
+binned_sah_builder.hpp:216-281, MBVH-RS traversal of stream_bvh_kernel.cpp:18-148).  Both builders: the device LBVH and the
+host binned SAH.  Bit-exact under the device's tie rule (lowest primitive index); under the reference's rule (first met in ITS
+tree) only a handful of rays may differ."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, random_rays
+
+pytestmark = pytest.mark.gpu
+
+N_TRI, W, H, SPP = 10_000_000, 3840, 2160, 4
+# tiles compared with the oracle: corners, centre, the 16-row edge band at the bottom (2160 = 67 * 32 + 16), the last column
+TILES = [(0, 0, 32, 32), (1920, 1088, 32, 32), (3808, 0, 32, 32), (640, 1600, 32, 32), (2560, 480, 32, 32),
+         (0, 2144, 32, 16), (1888, 2144, 32, 16), (3808, 2144, 32, 16)]
+
+
+@pytest.fixture(scope="module")
+def c4(orc):
+    from phosphorus_mk2_amd import scenes
+    t0 = time.time()
+    sc = scenes.soup(N_TRI, width=W, height=H)
+    t1 = time.time()
+    O = orc.Oracle(sc, spp=SPP)
+    print(f"\n[config 4] soup {t1 - t0:.1f} s, oracle reference-layout BVH {time.time() - t1:.1f} s: {O.bvh_info()}")
+    yield sc, O
+    O.close()
+
+
+def _camera_rays(n, seed):
+    """rays from the camera through random film positions (the kind the frame starts with) — origin 0, looking down -z"""
+    rng = np.random.default_rng(seed)
+    zoom = 1.12 * np.tan(1.9 / 2)
+    x = (rng.random(n) - 0.5) * (W / H) * zoom
+    y = (rng.random(n) - 0.5) * zoom
+    d = np.stack([x, y, -np.ones(n)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.zeros((n, 3), np.float32), d.astype(np.float32), np.full(n, np.finfo(np.float32).max, np.float32)
+
+
+@pytest.mark.parametrize("builder", ["device", "host"])
+def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
+    from phosphorus_mk2_amd import xpu
+    xpu.load_library()
+    sc, O = c4
+    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=SPP, paths_per_sample=1, path_depth=9, bvh_builder=builder))[0]
+    t0 = time.time()
+    dev.preprocess(sc)
+    st = dev.stats()
+    print(f"\n[config 4/{builder}] preprocess {time.time() - t0:.1f} s (tree {st['bvh_build_ms']:.0f} ms), {st['bvh_nodes']} nodes, "
+          f"{st['bvh_bytes'] / 1e6:.0f} MB, depth {st['bvh_depth']}; k_trace plan: block {st['trace_block']}, "
+          f"{st['trace_ntop']} elements in LDS, {st['trace_levels']} stack levels, {st['trace_waves_per_cu']} waves/CU")
+    # (c) the launch plan this tree runs with (kernels.hip: trace_plan): consistent with the depth and with the CU's 160 KB of LDS
+    assert st["triangles"] == N_TRI + 2 and st["bvh_bytes"] > 600e6
+    assert 8 <= st["bvh_depth"] <= 64 and st["trace_levels"] == max(2, st["bvh_depth"] - 1)
+    assert st["trace_block"] in (256, 512, 1024) and st["trace_ntop"] >= 9 and st["trace_waves_per_cu"] >= 8
+    # the 100 k soup (depth 7) runs 1024-thread workgroups with 32 waves per CU; a tree this deep must have re-planned
+    assert st["trace_levels"] >= 8
+
+    # (a) stage level: 16 k random rays inside the cloud + 8 k camera rays; closest hit and any hit
+    o1, d1, t1 = random_rays(16384, 41)
+    o2, d2, t2 = _camera_rays(8192, 42)
+    o = np.concatenate([o1, o2]); d = np.concatenate([d1, d2]); tm = np.concatenate([t1, t2])
+    g = dev.trace(o, d, tm)
+    orc.set_tie_rule(1)
+    try:
+        r = O.trace(o, d, tm)                                    # MBVH-RS on the reference-layout tree, device tie rule
+        nb = 256
+        rb = O.trace(o[:nb], d[:nb], tm[:nb], brute=True)        # linear_mbvh_kernel_t semantics: all 10 M triangles
+    finally:
+        orc.set_tie_rule(0)
+    assert g["hit"].mean() > 0.7
+    assert np.array_equal(g["prim"], r["prim"])
+    assert bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    assert np.array_equal(g["prim"][:nb], rb["prim"]) and bits_equal(g["t"][:nb], rb["t"])
+    r0 = O.trace(o, d, tm)                                       # the reference's own tie rule: first met wins
+    assert (g["prim"] != r0["prim"]).sum() <= 4 and bits_equal(g["t"], r0["t"])
+    tm2 = np.full(len(tm), 0.05, np.float32)                     # mean free path of this cloud is ~0.04
+    gs = dev.trace(o, d, tm2, shadow=True)
+    rs = O.trace(o, d, tm2, shadow=True)
+    assert np.array_equal(gs["hit"], rs["hit"]) and 0.05 < gs["hit"].mean() < 0.95
+
+    # (b) the whole 3840x2160 frame at 4 spp on this GPU; 8 tiles of it (edge band and last column included) against the oracle
+    film = xpu.Film(W, H, 4)
+    dev.start(sc, xpu.FrameState(7, xpu.Tiles.make(W, H, 32), film, native_sink=True))
+    dev.join()
+    fs = dev.stats()
+    dev.close()
+    assert fs["camera_samples"] == W * H * SPP and fs["tiles"] == 120 * 68 and np.isfinite(film.data).all()
+    assert fs["rays_closest"] > fs["camera_samples"] and fs["rays_shadow"] > 0
+    orc.set_tie_rule(1)
+    try:
+        ref, ost = O.render(rng=orc.RNG_COUNTER, seed=7, threads=16, tiles=TILES)
+    finally:
+        orc.set_tie_rule(0)
+    for (x, y, w, h) in TILES:
+        assert bits_equal(film.data[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3]), (x, y)
+    assert ref[..., :3].max() > 0.0

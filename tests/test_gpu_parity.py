@@ -53,12 +53,22 @@ def test_trace_edge_cases(xpu, orc):
     sc = scenes.cornell(64, 64)
     dev = _device(xpu, sc)
     O = orc.Oracle(sc, spp=1)
-    # axis-parallel directions (zero components), rays starting on surfaces, zero-length and huge tmax
-    o = np.array([[0.1, 0.3, 0], [0, 0, -2.5], [0.5, -1.0, -2.5], [0, 0, -2.5], [0, 0, -2.5], [0, 0.99, -2.5], [5, 5, 5]], np.float32)
-    d = np.array([[0, 0, -1], [0, 1, 0], [0, 1, 0], [1, 0, 0], [0, -1, 0], [0, -1, 0], [1, 0, 0]], np.float32)
-    tm = np.array([3.4e38, 3.4e38, 3.4e38, 0.0, 1e-6, 3.4e38, 3.4e38], np.float32)
-    g = dev.trace(o, d, tm); r = O.trace(o, d, tm, brute=True)
-    assert np.array_equal(g["prim"], r["prim"]) and bits_equal(g["t"], r["t"])
+    # axis-parallel directions (zero components), rays starting on surfaces, zero-length and huge tmax; the first ray runs
+    # exactly into the shared edge (the diagonal) of the back wall's two triangles — the commonest tie of real meshes
+    o = np.array([[0, 0, 0], [0.1, 0.3, 0], [0, 0, -2.5], [0.5, -1.0, -2.5], [0, 0, -2.5], [0, 0, -2.5], [0, 0.99, -2.5], [5, 5, 5]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, -1], [0, 1, 0], [0, 1, 0], [1, 0, 0], [0, -1, 0], [0, -1, 0], [1, 0, 0]], np.float32)
+    tm = np.array([3.4e38, 3.4e38, 3.4e38, 3.4e38, 0.0, 1e-6, 3.4e38, 3.4e38], np.float32)
+    g = dev.trace(o, d, tm)
+    orc.set_tie_rule(1)  # both triangles of the wall are hit at bitwise the same distance: the lower primitive index wins
+    try:
+        r = O.trace(o, d, tm, brute=True); rs = O.trace(o, d, tm)
+    finally:
+        orc.set_tie_rule(0)
+    assert np.array_equal(g["prim"], r["prim"]) and bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    assert np.array_equal(g["prim"], rs["prim"]) and bits_equal(g["t"], rs["t"])
+    assert g["prim"][0] == 4 and g["t"][0] == np.float32(3.5)  # back wall = mesh 2 = primitives 4 and 5; the tie goes to 4
+    r0 = O.trace(o, d, tm, brute=True)  # the reference's rule (first met wins) may pick the other triangle of the tie, nothing else
+    assert bits_equal(g["t"], r0["t"]) and np.array_equal(g["prim"][1:], r0["prim"][1:]) and r0["prim"][0] in (4, 5)
     assert dev.trace(o[:0], d[:0], tm[:0])["t"].shape == (0,)  # empty input
     dev.close()
 
@@ -153,6 +163,20 @@ def test_render_all_closures_matches_oracle(xpu, orc):
     assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
     fin = np.isfinite(ref[..., :3]).all(axis=-1)
     assert np.array_equal(fin, np.isfinite(film[..., :3]).all(axis=-1))
+    assert max_pixel_l2(film[fin], ref[fin]) < L2_TOL
+    assert bits_equal(film[..., :3][fin], ref[..., :3][fin])
+
+
+def test_general_closures_at_film_size(xpu, orc):
+    """the general k_shade (all seven lobe models, 16 closure recipes: the declared stand-in of the BMW configs) on a 640x360
+    film with an edge band (360 = 11 * 32 + 8), whole frame against the oracle"""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.multi_material_soup(20000, width=640, height=360)
+    film, st, (ref, ost) = _render_both(xpu, orc, sc, spp=4, seed=17, threads=16)
+    assert st["camera_samples"] == 640 * 360 * 4
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"]
+    fin = np.isfinite(ref[..., :3]).all(axis=-1)
+    assert fin.mean() > 0.999 and np.array_equal(fin, np.isfinite(film[..., :3]).all(axis=-1))
     assert max_pixel_l2(film[fin], ref[fin]) < L2_TOL
     assert bits_equal(film[..., :3][fin], ref[..., :3][fin])
 
@@ -343,6 +367,35 @@ def test_hybrid_cpu_gpu_share_one_tile_queue(xpu, orc):
     ref, _ = O.render(rng=orc.RNG_COUNTER, seed=6, threads=4)
     assert bits_equal(film.data[..., :3], ref[..., :3])
     dev.close()
+
+
+def test_two_devices_drain_one_tile_queue(xpu, orc):
+    """The reference's multi-device mechanism (src/core.cpp:103-115): every xpu_t of discover() drains the SAME job::tiles_t
+    and adds its tiles to the SAME film.  Two phx_device objects (both on this box's one GPU, ordinal 0) share one native
+    queue and one film; whoever renders a tile, the film equals the one-device film and the oracle's, bit for bit."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(5000, width=320, height=208)  # 70 tiles, a 16-row edge band
+    one, st1 = xpu.render(sc, spp=9, seed=4)
+    opts = xpu.Options(samples_per_pixel=9, paths_per_sample=1, tiles_per_batch=3, device_ordinal=0)
+    devs = [xpu.HipDevice.make(opts), xpu.HipDevice.make(opts)]
+    for dv in devs:
+        dv.preprocess(sc)
+    for sink in ("callback", "native"):
+        tiles = xpu.Tiles.make(320, 208, 32)
+        film = xpu.Film(320, 208, 4)
+        for dv in devs:
+            dv.start(sc, xpu.FrameState(4, tiles, film, native_sink=(sink == "native")))
+        for dv in devs:
+            dv.join()
+        sts = [dv.stats() for dv in devs]
+        assert sum(s["tiles"] for s in sts) == len(tiles) == 70
+        for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked"):
+            assert sum(s[k] for s in sts) == st1[k]
+        assert bits_equal(film.data, one)
+    for dv in devs:
+        dv.close()
+    ref, _ = orc.Oracle(sc, spp=9).render(rng=orc.RNG_COUNTER, seed=4, threads=8)
+    assert bits_equal(one[..., :3], ref[..., :3])
 
 
 def test_error_behaviour(xpu):
