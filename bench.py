@@ -48,7 +48,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-tiles", type=int, default=100000, help="tiles of the frame in the CPU baseline sample")
     p.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel in the CPU baseline sample")
-    p.add_argument("--bvh-builder", choices=["host", "device"], default="host", help="host binned SAH (default) or device LBVH")
+    p.add_argument("--bvh-builder", choices=["auto", "host", "device"], default="auto", help="auto (host binned SAH up to 2 M triangles, device LBVH above), host, device")
     p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
     return p.parse_args()
 

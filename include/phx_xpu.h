@@ -61,10 +61,13 @@ typedef struct phx_options {
   int32_t  device_ordinal;    /* HIP device index; -1 = current device */
   uint32_t samples_in_flight; /* samples of one pixel carried per wavefront pass */
   uint32_t tiles_per_batch;   /* tiles pulled from the queue per pass */
-  uint32_t bvh_builder;       /* PHX_BVH_HOST_SAH (default) or PHX_BVH_DEVICE_LBVH: where preprocess builds the tree */
+  uint32_t bvh_builder;       /* PHX_BVH_AUTO (default), PHX_BVH_DEVICE_LBVH or PHX_BVH_HOST_SAH: where preprocess builds the tree */
   uint32_t reserved[5];
 } phx_options;
-enum { PHX_BVH_HOST_SAH = 0, PHX_BVH_DEVICE_LBVH = 1 };
+/* AUTO: binned SAH on the host cores up to 2 M triangles (traces 2-8 % faster, builds 1 M triangles in ~0.6 s), LBVH on the device
+ * above (10 M triangles in 0.1 s instead of 7 s, and no slower to trace at that size) — cpu_t::preprocess rebuilds its
+ * accelerator on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the interface's cost. */
+enum { PHX_BVH_AUTO = 0, PHX_BVH_DEVICE_LBVH = 1, PHX_BVH_HOST_SAH = 2 };
 
 /* ---- scene: what the device reads through scene_t (src/scene.hpp:14-50) --------------- */
 
@@ -189,6 +192,16 @@ typedef struct phx_stats {
   uint64_t trace_waves_per_cu; /* resident k_trace waves per compute unit with that LDS footprint */
   uint64_t bvh_depth;        /* levels of the 8-wide tree (<= 64) */
   uint64_t paths_in_flight;  /* paths carried per wavefront pass in the last frame (pixels of a batch x samples) */
+  /* traversal work of the last frame — filled only by the instrumented build (make variant NAME=count EXTRA=-DPHX_COUNT=1),
+   * 0 otherwise; [0] closest-hit rays, [1] shadow rays */
+  uint64_t node_visits_lds[2]; /* nodelets read from the top of the tree staged in LDS */
+  uint64_t node_visits_mem[2]; /* nodelets read through the vector L1 (4 x 16 B per lane) */
+  uint64_t tri_tests[2];       /* triangle records read through the vector L1 (3 x 16 B per lane) and tested */
+  uint64_t instrumented;       /* 1 if this library counts them */
+  uint64_t wave_iters;         /* instrumented: k_trace loop iterations summed over waves */
+  uint64_t node_block_execs;   /* instrumented: iterations in which at least one lane visited a node */
+  uint64_t tri_block_execs;    /* instrumented: iterations in which at least one lane tested a triangle */
+  uint64_t refills;            /* instrumented: refill rounds summed over waves */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

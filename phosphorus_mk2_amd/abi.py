@@ -11,7 +11,7 @@ LOBE_EMISSIVE, LOBE_DIFFUSE, LOBE_OREN_NAYAR, LOBE_REFLECTION = 0, 1, 2, 4
 LOBE_REFRACTION, LOBE_MICROFACET, LOBE_SHEEN, LOBE_BACKGROUND, LOBE_TRANSPARENT = 8, 16, 32, 64, 128
 BSDF_DIFFUSE, BSDF_GLOSSY, BSDF_SPECULAR, BSDF_REFLECT, BSDF_TRANSMIT = 1, 2, 4, 8, 16
 MAX_LOBES = 8
-BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
+BVH_AUTO, BVH_DEVICE_LBVH, BVH_HOST_SAH = 0, 1, 2
 MESH_UV_PER_VERTEX, MESH_NORMALS_PER_VERTEX = 1, 2
 
 f32p = C.POINTER(C.c_float)
@@ -93,6 +93,9 @@ class Stats(C.Structure):
         ("preprocess_ms", C.c_double), ("bvh_build_ms", C.c_double),
         ("trace_block", C.c_uint64), ("trace_ntop", C.c_uint64), ("trace_levels", C.c_uint64), ("trace_waves_per_cu", C.c_uint64),
         ("bvh_depth", C.c_uint64), ("paths_in_flight", C.c_uint64),
+        ("node_visits_lds", C.c_uint64 * 2), ("node_visits_mem", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2),
+        ("instrumented", C.c_uint64), ("wave_iters", C.c_uint64), ("node_block_execs", C.c_uint64), ("tri_block_execs", C.c_uint64),
+        ("refills", C.c_uint64),
     ]
 
 

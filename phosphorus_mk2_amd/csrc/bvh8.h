@@ -1,9 +1,12 @@
-// bvh8.h — the device's acceleration structure: an 8-wide BVH with 80-byte quantised nodes
-// ("nodelets": five 16-B words, child boxes as 8-bit grid coordinates relative to the node's own
-// box) and 48-byte Moeller-Trumbore triangle records (v0, e0, e1, primitive id).  It takes the
-// place of accel::mbvh_t (reference src/accel/bvh.hpp:17-49: 288-B nodes, 384-B packets) and of
-// the stream traversal in src/kernels/cpu/stream_bvh_kernel.cpp:18-148, redesigned for one ray
-// per lane on a 64-lane wavefront:
+// bvh8.h — the device's acceleration structure: an 8-wide BVH stored as ONE pool of 64-byte elements.  An element is
+// either a quantised node ("nodelet": four 16-B words — grid origin, scale exponents, child masks and child base in the
+// first, child boxes as 8-bit grid coordinates relative to the node's own origin in the other three) or a Moeller-Trumbore
+// triangle record (v0, e0, e1, primitive id, material).  The children of a node — nodelets and triangle records alike, one
+// triangle per leaf slot — are contiguous in slot order, so a node needs ONE 32-bit base, and every element is 64-B aligned:
+// a 128-B cache line holds exactly two siblings.  It takes the place of accel::mbvh_t (reference src/accel/bvh.hpp:17-49:
+// 288-B nodes, 384-B packets) and of the stream traversal in src/kernels/cpu/stream_bvh_kernel.cpp:18-148, redesigned for
+// one ray per lane on a 64-lane wavefront:
+//   * a node visit is four 16-B loads per lane (the vector L1 charges per lane address, profiles/README.md),
 //   * children are stored in "octant order" slots so the visiting order comes from the ray's sign
 //     bits alone — no per-lane distance sort, no per-child ray lists (the MBVH-RS lanes_t),
 //   * one stack entry is a (base, hit-bitmask) group, so the per-lane stack is <= tree depth,
@@ -17,33 +20,43 @@
 
 namespace phx {
 
+// Node origins live on a per-scene grid of 2^18 cells per axis: origin = fma(i, cell, lo) — the SAME fma on the host, in the
+// device builder and in the traversal, so the decoded origin is one well-defined float.  The builders pick i so that the
+// decoded origin does not exceed the node's true lower corner and quantise the child boxes outwards relative to it.
+struct SceneGrid { float lo[3], cell[3]; };
+#define PHX_GRID_BITS 18
+#define PHX_GRID_MAX ((1u << PHX_GRID_BITS) - 1u)
+
 struct alignas(16) Node8 {
-  float px, py, pz;           // origin of the quantisation grid (node box min)
-  uint8_t ex, ey, ez, imask;  // grid scale exponents (biased like fp32), bit i of imask: child slot i is an inner node
-  uint32_t child_base;        // index of this node's first inner child (children are contiguous, in slot order)
-  uint32_t tri_base;          // index of this node's first triangle record
-  uint32_t tmask;             // bit (s + 8*j), j < 3: leaf slot s holds a j-th triangle; records are stored in bit order
-  uint32_t pad;
+  uint32_t origin_lo, origin_hi;  // bits 0..17 ix | 18..35 iy | 36..53 iz | 54..61 valid mask (bit s: child slot s is in use)
+  uint8_t ex, ey, ez, imask;      // grid scale exponents (biased like fp32); bit s of imask: child slot s is an inner node
+  uint32_t child_base;            // pool index of the first child; the children of the used slots are contiguous, in slot order
   uint8_t qlox[8], qloy[8], qloz[8], qhix[8], qhiy[8], qhiz[8];
 };
-static_assert(sizeof(Node8) == 80, "Node8 must be five 16-byte words");
+static_assert(sizeof(Node8) == 64, "Node8 must be four 16-byte words");
 
-struct TriRec {  // 48 B: three 16-byte words
+struct alignas(16) TriRec {  // 64 B: three 16-byte words that the traversal reads + one spare word
   float v0x, v0y, v0z, e0x;
   float e0y, e0z, e1x, e1y;
   float e1z;
   uint32_t prim;      // index in scene_t::triangles() order
-  uint32_t material;  // material | smooth << 31 (filled by the device after the build: saves k_shade a dependent load)
+  uint32_t material;  // material | smooth << 31 (saves k_shade a dependent load)
   uint32_t pad1;
+  uint32_t pad2[4];
 };
-static_assert(sizeof(TriRec) == 48, "TriRec must be three 16-byte words");
+static_assert(sizeof(TriRec) == 64, "TriRec shares the 64-byte pool with Node8");
+
+union PoolElem { Node8 node; TriRec tri; uint32_t w[16]; };  // host-side view of one pool element
+static_assert(sizeof(PoolElem) == 64, "pool elements are 64 bytes");
 
 // One depth limit for every consumer of the tree: the builders refuse deeper trees, k_trace / k_trace_rays size their per-lane
 // LDS stacks from the depth (<= 64 levels x 256 lanes x 8 B = 128 KB of the CU's 160 KB).
 #define PHX_MAX_BVH_DEPTH 64
-#define PHX_NODE_LDS_BYTES 80u  /* bytes a staged nodelet occupies in LDS */
+// A nodelet staged in LDS keeps an 80-byte stride: with 64 the k-th word of every staged nodelet would fall on 4 of the 16
+// 16-byte bank slots (4-way conflicts on a random gather); 5 slots per element spread them over all 16.
+#define PHX_NODE_LDS_BYTES 80u
 
-struct Hit { float t, u, v; uint32_t tri; };  // tri = index of the TriRec, 0xffffffff = miss
+struct Hit { float t, u, v; uint32_t tri; };  // tri = pool index of the TriRec, 0xffffffff = miss
 
 PHX_HD int clz32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -60,6 +73,40 @@ PHX_HD int popc32(uint32_t x) {
 #endif
 }
 PHX_HD float u32_as_f32(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+
+PHX_HD void node_origin_encode(Node8& nd, uint32_t ix, uint32_t iy, uint32_t iz, uint32_t valid) {
+  const unsigned long long v = (unsigned long long)ix | ((unsigned long long)iy << 18) | ((unsigned long long)iz << 36) | ((unsigned long long)valid << 54);
+  nd.origin_lo = (uint32_t)v; nd.origin_hi = (uint32_t)(v >> 32);
+}
+// origin and valid mask of a node from its first two words
+PHX_HD void node_origin_decode(uint32_t w0, uint32_t w1, const SceneGrid& g, float& px, float& py, float& pz, uint32_t& valid) {
+  const uint32_t ix = w0 & PHX_GRID_MAX, iy = ((w0 >> 18) | (w1 << 14)) & PHX_GRID_MAX, iz = (w1 >> 4) & PHX_GRID_MAX;
+  px = fmaf((float)ix, g.cell[0], g.lo[0]);
+  py = fmaf((float)iy, g.cell[1], g.lo[1]);
+  pz = fmaf((float)iz, g.cell[2], g.lo[2]);
+  valid = (w1 >> 22) & 0xffu;
+}
+// largest grid index whose decoded coordinate does not exceed x (0 when x lies below the grid)
+PHX_HD uint32_t grid_index_below(float x, float lo, float cell) {
+  double t = floor(((double)x - (double)lo) / (double)cell);
+  if (!(t > 0.0)) t = 0.0;
+  if (t > (double)PHX_GRID_MAX) t = (double)PHX_GRID_MAX;
+  uint32_t i = (uint32_t)t;
+  while (i > 0u && fmaf((float)i, cell, lo) > x) --i;
+  return i;
+}
+// the scene grid of a bounding box [lo, hi]: 2^18 - 1 cells of equal size per axis, a positive cell even for flat extents
+PHX_HD SceneGrid make_scene_grid(const float* lo, const float* hi) {
+  SceneGrid g;
+  for (int a = 0; a < 3; ++a) {
+    g.lo[a] = lo[a];
+    const double ext = (double)hi[a] - (double)lo[a];
+    float c = (float)(ext / (double)PHX_GRID_MAX);
+    if (!(c > 0.0f) || !(c < 3.0e38f)) c = 1.0e-30f;
+    g.cell[a] = c;
+  }
+  return g;
+}
 
 // Reference Moeller-Trumbore (src/accel/triangle.hpp:149-164) for one ray and one triangle.
 // `best_prim`: primitive of the hit that set tmax (0 while the ray has none).  Two triangles can be hit at bitwise the same
@@ -83,19 +130,30 @@ PHX_HD bool mt_intersect(const TriRec& T, const v3& o, const v3& wi, float tmax,
   return vmask && umask && dmask && xmask;
 }
 
-// The 8 box tests of one node for one ray.  Returns the CWBVH-style hit mask: inner children set
-// bit 24 + (slot ^ oct_inv), the triangles of a hit leaf child set their bits in [0,24).
 struct RayCtx {
   v3 o, d;
   float idx, idy, idz;   // clamped reciprocal direction
   uint32_t oct_inv;      // (dx>=0?4:0)|(dy>=0?2:0)|(dz>=0?1:0)
 };
+// The reciprocal direction only feeds the conservative box tests, never a result: on the device it is the hardware's v_rcp_f32
+// (1 ulp) instead of an IEEE division (10 instructions each, three per ray: k_trace is VALU-issue bound); the slab ends are
+// padded by 4 ulp (node_hit8), which covers it.
+#ifndef PHX_FAST_RCP
+#define PHX_FAST_RCP 1
+#endif
+PHX_HD float ray_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && PHX_FAST_RCP
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
 PHX_HD RayCtx make_ray_ctx(const v3& o, const v3& d) {
   RayCtx r; r.o = o; r.d = d;
   const float big = 1e20f, tiny = 1e-20f;
-  r.idx = fabsf(d.x) > tiny ? 1.0f / d.x : (d.x < 0.0f ? -big : big);
-  r.idy = fabsf(d.y) > tiny ? 1.0f / d.y : (d.y < 0.0f ? -big : big);
-  r.idz = fabsf(d.z) > tiny ? 1.0f / d.z : (d.z < 0.0f ? -big : big);
+  r.idx = fabsf(d.x) > tiny ? ray_rcp(d.x) : (d.x < 0.0f ? -big : big);
+  r.idy = fabsf(d.y) > tiny ? ray_rcp(d.y) : (d.y < 0.0f ? -big : big);
+  r.idz = fabsf(d.z) > tiny ? ray_rcp(d.z) : (d.z < 0.0f ? -big : big);
   r.oct_inv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
   return r;
 }
@@ -112,31 +170,36 @@ PHX_HD uint32_t perm_xor8(uint32_t x, uint32_t oct) {
 // Conservative: entry distance scaled by (1 - 2^-21), exit distance by (1 + 2^-21) (4 ulp each; tn >= 0, and a
 // negative exit distance is a miss either way), IEEE maxNum/minNum.  On the device the near/far planes of an
 // axis go through one packed FMA (v_pk_fma_f32) and the two pads through one packed multiply.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float phx_f2 __attribute__((ext_vector_type(2)));
+#ifndef PHX_PACKED_FMA
+#define PHX_PACKED_FMA 0  /* measured: plain v_fma_f32 0.8-1.2 % faster than v_pk_fma_f32 here (a packed op takes two issue slots and needs its operands in register pairs) */
 #endif
-PHX_HD uint32_t node_hit8(const uint32_t* w /* 20 words of the node */, const RayCtx& r, float tmax) {
-  const float px = u32_as_f32(w[0]), py = u32_as_f32(w[1]), pz = u32_as_f32(w[2]);
-  const uint32_t e = w[3];
+#if defined(__HIP_DEVICE_COMPILE__) && PHX_PACKED_FMA
+#define PHX_USE_PK 1
+typedef float phx_f2 __attribute__((ext_vector_type(2)));
+#else
+#define PHX_USE_PK 0
+#endif
+PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px, float py, float pz, const RayCtx& r, float tmax) {
+  const uint32_t e = w[2];
   const float sx = u32_as_f32((e & 0xffu) << 23), sy = u32_as_f32(((e >> 8) & 0xffu) << 23), sz = u32_as_f32(((e >> 16) & 0xffu) << 23);
   const float ax = sx * r.idx, ay = sy * r.idy, az = sz * r.idz;
   const float bx = (px - r.o.x) * r.idx, by = (py - r.o.y) * r.idy, bz = (pz - r.o.z) * r.idz;
   const bool nx = r.idx < 0.0f, ny = r.idy < 0.0f, nz = r.idz < 0.0f;
   const float pad_near = 0.999999523162841796875f, pad_far = 1.000000476837158203125f;  // 1 -/+ 2^-21
-  // words: 8,9 qlox | 10,11 qloy | 12,13 qloz | 14,15 qhix | 16,17 qhiy | 18,19 qhiz
+  // words: 4,5 qlox | 6,7 qloy | 8,9 qloz | 10,11 qhix | 12,13 qhiy | 14,15 qhiz
   uint32_t hit8 = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if PHX_USE_PK
   const phx_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz}, pad2 = {pad_near, pad_far};
 #endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const uint32_t nearx = nx ? w[14 + half] : w[8 + half], farx = nx ? w[8 + half] : w[14 + half];
-    const uint32_t neary = ny ? w[16 + half] : w[10 + half], fary = ny ? w[10 + half] : w[16 + half];
-    const uint32_t nearz = nz ? w[18 + half] : w[12 + half], farz = nz ? w[12 + half] : w[18 + half];
+    const uint32_t nearx = nx ? w[10 + half] : w[4 + half], farx = nx ? w[4 + half] : w[10 + half];
+    const uint32_t neary = ny ? w[12 + half] : w[6 + half], fary = ny ? w[6 + half] : w[12 + half];
+    const uint32_t nearz = nz ? w[14 + half] : w[8 + half], farz = nz ? w[8 + half] : w[14 + half];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sh = 8 * j;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if PHX_USE_PK
       const phx_f2 qx = {(float)((nearx >> sh) & 0xffu), (float)((farx >> sh) & 0xffu)};
       const phx_f2 qy = {(float)((neary >> sh) & 0xffu), (float)((fary >> sh) & 0xffu)};
       const phx_f2 qz = {(float)((nearz >> sh) & 0xffu), (float)((farz >> sh) & 0xffu)};
@@ -162,55 +225,63 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 20 words of the node */, const Ra
   return hit8;
 }
 
-// CWBVH-style hit mask of a node: inner children set bit 24 + (slot ^ oct_inv) (so that "highest bit first"
-// visits them in the ray's octant order), the triangles of hit leaf slots set their bits in [0,24).
-PHX_HD uint32_t node_hitmask(const uint32_t* w, const RayCtx& r, float tmax) {
-  const uint32_t hit8 = node_hit8(w, r, tmax);
-  const uint32_t imask = w[3] >> 24;
-  const uint32_t leaf = hit8 & ~imask;
-  return (perm_xor8(hit8 & imask, r.oct_inv) << 24) | ((leaf | (leaf << 8) | (leaf << 16)) & w[6]);
+// Hit mask of a node for one ray: bits 24..31 = hit inner children, XOR-permuted by the ray's octant so that "highest bit
+// first" visits them front to back; bits 16..23 = hit leaf children (triangles) by slot — they are tested before the walk
+// descends, in slot order: their order changes no result (the closest hit and its tie rule do not depend on it) and walking
+// nodelets and triangles in one front-to-back order measured 3 % slower; bits 0..7 = the node's valid mask (the rank of a slot
+// among the valid ones is its child's offset from child_base).  `perm8(mask)` is the octant permutation: perm_xor8 in plain
+// code, a 2 KB table in LDS inside k_trace (k_trace is VALU-issue bound: the table is 4 % faster, profiles/README.md).
+template <typename Perm>
+PHX_HD uint32_t node_hitmask(const uint32_t* w, const SceneGrid& g, const RayCtx& r, float tmax, Perm&& perm8) {
+  float px, py, pz; uint32_t valid;
+  node_origin_decode(w[0], w[1], g, px, py, pz, valid);
+  const uint32_t hit8 = node_hit8(w, px, py, pz, r, tmax) & valid;
+  const uint32_t imask = w[2] >> 24;
+  return (perm8(hit8 & imask) << 24) | ((hit8 & ~imask) << 16) | valid;
+}
+PHX_HD uint32_t node_hitmask(const uint32_t* w, const SceneGrid& g, const RayCtx& r, float tmax) {
+  return node_hitmask(w, g, r, tmax, [&](uint32_t m) { return perm_xor8(m, r.oct_inv); });
 }
 
 // Closest-hit (ANY=false) or any-hit (ANY=true) traversal of one ray.  Stack: push(uint32,uint32),
 // pop(uint32&,uint32&), empty().  Counters are optional (host-side validation only).
+// State of a node group: `base` = child_base of the parent, `hits` = (pending inner hits << 24) | valid mask of the parent.
 template <bool ANY, typename Stack>
-PHX_HD bool traverse8(const uint32_t* __restrict__ nodes /* 20 words per node */, const TriRec* __restrict__ tris,
+PHX_HD bool traverse8(const uint32_t* __restrict__ pool /* 16 words per element */, const SceneGrid& grid,
                       const v3& o, const v3& d, float tmax, Hit& hit, Stack& stack,
                       uint32_t* node_visits = nullptr, uint32_t* tri_tests = nullptr) {
   const RayCtx r = make_ray_ctx(o, d);
   hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xffffffffu;
   uint32_t best_prim = 0;
-  uint32_t ng_base = 0, ng_hits = 0x80000000u;  // the root as a one-child group
+  uint32_t ng_base = 0, ng_hits = 0x80000000u;  // the root as a one-child group (valid byte 0: its rank is 0 whatever the octant)
   for (;;) {
     // visit the nearest not-yet-visited inner child of the current group
     const uint32_t bit = 31u - (uint32_t)clz32(ng_hits);
     const uint32_t rest = ng_hits & ~(1u << bit);
     if (rest > 0x00ffffffu) stack.push(ng_base, rest);
     const uint32_t slot = (bit - 24u) ^ r.oct_inv;
-    const uint32_t rel = (uint32_t)popc32(ng_hits & 0xffu & ~(0xffffffffu << slot));
-    const uint32_t ni = ng_base + rel;
-    uint32_t w[20];
+    const uint32_t ni = ng_base + (uint32_t)popc32(ng_hits & 0xffu & ~(0xffffffffu << slot));
+    uint32_t w[16];
     {
-      const uint32_t* src = nodes + (size_t)ni * 20u;
+      const uint32_t* src = pool + (size_t)ni * 16u;
 #if defined(__HIP_DEVICE_COMPILE__)
       const uint4* s4 = reinterpret_cast<const uint4*>(src);
 #pragma unroll
-      for (int k = 0; k < 5; ++k) { uint4 q = s4[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+      for (int k = 0; k < 4; ++k) { uint4 q = s4[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
 #else
-      for (int k = 0; k < 20; ++k) w[k] = src[k];
+      for (int k = 0; k < 16; ++k) w[k] = src[k];
 #endif
     }
     if (node_visits) ++*node_visits;
-    const uint32_t hm = node_hitmask(w, r, hit.t);
-    ng_base = w[4];
-    ng_hits = (hm & 0xff000000u) | (w[3] >> 24);
-    uint32_t th = hm & 0x00ffffffu;
-    const uint32_t tb = w[5], tm = w[6];
+    const uint32_t hm = node_hitmask(w, grid, r, hit.t);
+    ng_base = w[3];
+    ng_hits = hm & 0xff0000ffu;
+    uint32_t th = (hm >> 16) & 0xffu;
     while (th) {
       const uint32_t k = 31u - (uint32_t)clz32(th);
       th &= ~(1u << k);
-      const uint32_t ti = tb + (uint32_t)popc32(tm & ~(0xffffffffu << k));
-      const TriRec T = tris[ti];
+      const uint32_t ti = ng_base + (uint32_t)popc32(hm & 0xffu & ~(0xffffffffu << k));
+      const TriRec T = *reinterpret_cast<const TriRec*>(pool + (size_t)ti * 16u);
       float us, vs, ds;
       if (tri_tests) ++*tri_tests;
       if (mt_intersect(T, o, d, hit.t, best_prim, us, vs, ds)) {

@@ -1,4 +1,4 @@
-// bvh_gpu.h — device-side LBVH build of the BVH8 of bvh8.h (see bvh_gpu.hip).
+// bvh_gpu.h — device-side LBVH build of the BVH8 pool of bvh8.h (see bvh_gpu.hip).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -10,9 +10,10 @@
 namespace phx {
 
 struct GpuBvh {
-  Node8* nodes;   // hipMalloc'd, owned by the caller after a successful build
-  TriRec* tris;   // hipMalloc'd, material word already filled
+  PoolElem* pool;      // hipMalloc'd (2 x triangles elements reserved), owned by the caller after a successful build
+  uint32_t num_elems;  // elements in use: nodelets + triangle records (material word already filled)
   uint32_t num_nodes, num_tris, depth;
+  SceneGrid grid;      // the grid the nodelets' origins are stored on
 };
 
 // d_abc: 9 floats per primitive (a, b, c) in scene_t::triangles() order, device memory.

@@ -8,9 +8,10 @@
 //   rocprim::radix_sort_pairs                      (library radix sort of 8-byte keys: not a hot-path kernel)
 //   k_radix_tree    Karras 2012: one thread per internal node of the binary radix tree over the sorted codes
 //   k_fit           bottom-up boxes + leaf counts (second arrival at a node continues upwards)
-//   k_collapse      per BVH8 node, level by level: greedy surface-area expansion to <= 8 children (subtrees of
-//                   <= leaf_max triangles become leaf slots), octant-order slot assignment, outward quantisation,
-//                   triangle records in tmask bit order — the same node semantics as the host builder.
+//   k_collapse      per BVH8 node, level by level: greedy surface-area expansion to <= 8 children (single triangles become
+//                   leaf slots), octant-order slot assignment, origin on the scene grid, outward quantisation, the
+//                   children — nodelets and triangle records — allocated contiguously in the 64-byte pool, in slot
+//                   order: the same node semantics as the host builder.
 // Traversal results do not depend on which builder made the tree (conservative box tests, bvh8.h).
 #include "bvh_gpu.h"
 
@@ -36,9 +37,10 @@ __host__ __device__ inline float ord2f(uint32_t o) {
 
 struct Box6 { float lo[3], hi[3]; };
 
-__global__ void __launch_bounds__(GB) k_prim_bounds(const float* __restrict__ abc, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ cb /* 6 ordered uints */) {
+__global__ void __launch_bounds__(GB) k_prim_bounds(const float* __restrict__ abc, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ cb /* 12 ordered uints: centroid lo/hi, geometry lo/hi */) {
   const uint32_t i = blockIdx.x * GB + threadIdx.x;
   float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float glo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, ghi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   if (i < n) {
     const float* t = abc + 9 * (size_t)i;
     Box6 b;
@@ -46,13 +48,16 @@ __global__ void __launch_bounds__(GB) k_prim_bounds(const float* __restrict__ ab
       b.lo[a] = fminf(fminf(t[a], t[3 + a]), t[6 + a]);
       b.hi[a] = fmaxf(fmaxf(t[a], t[3 + a]), t[6 + a]);
       clo[a] = chi[a] = 0.5f * (b.lo[a] + b.hi[a]);
+      glo[a] = b.lo[a]; ghi[a] = b.hi[a];
     }
     pbox[i] = b;
   }
   for (int a = 0; a < 3; ++a) {
     float lo = clo[a], hi = chi[a];
     for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
-    if (__lane_id() == 0) { atomicMin(&cb[a], f2ord(lo)); atomicMax(&cb[3 + a], f2ord(hi)); }
+    float l2 = glo[a], h2 = ghi[a];
+    for (int o = 32; o > 0; o >>= 1) { l2 = fminf(l2, __shfl_xor(l2, o)); h2 = fmaxf(h2, __shfl_xor(h2, o)); }
+    if (__lane_id() == 0) { atomicMin(&cb[a], f2ord(lo)); atomicMax(&cb[3 + a], f2ord(hi)); atomicMin(&cb[6 + a], f2ord(l2)); atomicMax(&cb[9 + a], f2ord(h2)); }
   }
 }
 
@@ -159,22 +164,21 @@ __device__ __forceinline__ uint32_t first_prim(const Tree2& T, uint32_t node) {
 }
 
 
-// One thread builds one Node8 from BVH2 subtree `qa[e]` into node slot `qb[e]`.
-__global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restrict__ abc, const uint32_t* __restrict__ prim_material, const uint32_t* __restrict__ qa,
+// One thread builds one Node8 from BVH2 subtree `qa[e]` into pool element `qb[e]`.
+__global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const float* __restrict__ abc, const uint32_t* __restrict__ prim_material, const uint32_t* __restrict__ qa,
                                                  const uint32_t* __restrict__ qb, uint32_t count, uint32_t* __restrict__ qa_out, uint32_t* __restrict__ qb_out,
-                                                 uint32_t* __restrict__ counters /* [0] nodes, [1] tris, [2] out queue */, Node8* __restrict__ nodes,
-                                                 TriRec* __restrict__ tris, uint32_t LEAF_SLOT_MAX) {
+                                                 uint32_t* __restrict__ counters /* [0] pool elements, [1] tris, [2] out queue, [3] nodes */, PoolElem* __restrict__ pool) {
   const uint32_t e = blockIdx.x * 64 + threadIdx.x;
   if (e >= count) return;
   const uint32_t root2 = qa[e], n8 = qb[e];
   uint32_t ch[8]; int nch = 0;
-  if (leaf_count(T, root2) <= LEAF_SLOT_MAX) { ch[nch++] = root2; }  // degenerate: the whole tree is one leaf slot
+  if (leaf_count(T, root2) <= 1u) { ch[nch++] = root2; }  // degenerate: the whole tree is one triangle
   else {
     ch[nch++] = T.left[root2]; ch[nch++] = T.right[root2];
     while (nch < 8) {
       int pick = -1; float best = -1.0f;
       for (int i = 0; i < nch; ++i) {
-        if (leaf_count(T, ch[i]) <= LEAF_SLOT_MAX) continue;
+        if (leaf_count(T, ch[i]) <= 1u) continue;
         const float a = area6(T.nbox[ch[i]]);
         if (a > best) { best = a; pick = i; }
       }
@@ -201,11 +205,13 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restric
   for (int i = 0; i < nch; ++i) child_in_slot[slot_of[i]] = i;
 
   Node8 nd;
-  nd.px = nb.lo[0]; nd.py = nb.lo[1]; nd.pz = nb.lo[2];
-  nd.imask = 0; nd.tmask = 0; nd.pad = 0;
+  nd.imask = 0;
+  // origin on the scene grid, not above the node's lower corner; everything below is relative to the DECODED origin
+  uint32_t gi[3]; float org[3];
+  for (int a = 0; a < 3; ++a) { gi[a] = grid_index_below(nb.lo[a], grid.lo[a], grid.cell[a]); org[a] = fmaf((float)gi[a], grid.cell[a], grid.lo[a]); }
   double scale[3]; uint8_t eb[3];
   for (int a = 0; a < 3; ++a) {
-    const double ext = (double)(nb.hi[a] - nb.lo[a]);
+    const double ext = (double)nb.hi[a] - (double)org[a];
     int ex = -126;
     if (ext > 0.0) {
       ex = (int)ceil(log2(ext * 1.00001 / 255.0));
@@ -216,47 +222,48 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restric
     scale[a] = ldexp(1.0, ex);
   }
   nd.ex = eb[0]; nd.ey = eb[1]; nd.ez = eb[2];
-  uint32_t n_inner = 0, n_tri = 0;
+  uint32_t n_inner = 0, n_tri = 0, valid = 0;
   for (int s = 0; s < 8; ++s) {
     const int i = child_in_slot[s];
     uint8_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
     if (i >= 0) {
+      valid |= 1u << s;
       const Box6 b = T.nbox[ch[i]];
       for (int a = 0; a < 3; ++a) {
-        double lo = floor(((double)b.lo[a] - (double)nb.lo[a]) / scale[a] - 1e-3);
-        double hi = ceil(((double)b.hi[a] - (double)nb.lo[a]) / scale[a] + 1e-3);
+        double lo = floor(((double)b.lo[a] - (double)org[a]) / scale[a] - 1e-3);
+        double hi = ceil(((double)b.hi[a] - (double)org[a]) / scale[a] + 1e-3);
         lo = fmax(0.0, fmin(255.0, lo)); hi = fmax(0.0, fmin(255.0, hi));
         ql[a] = (uint8_t)lo; qh[a] = (uint8_t)hi;
       }
-      const uint32_t cnt = leaf_count(T, ch[i]);
-      if (cnt <= LEAF_SLOT_MAX) { for (uint32_t k = 0; k < cnt; ++k) nd.tmask |= 1u << (s + 8 * (int)k); n_tri += cnt; }
+      if (leaf_count(T, ch[i]) <= 1u) ++n_tri;
       else { nd.imask |= (uint8_t)(1u << s); ++n_inner; }
     }
     nd.qlox[s] = ql[0]; nd.qloy[s] = ql[1]; nd.qloz[s] = ql[2]; nd.qhix[s] = qh[0]; nd.qhiy[s] = qh[1]; nd.qhiz[s] = qh[2];
   }
-  nd.child_base = n_inner ? atomicAdd(&counters[0], n_inner) : 0u;
-  nd.tri_base = n_tri ? atomicAdd(&counters[1], n_tri) : 0u;
-  // triangle records in tmask bit order: bit (s + 8*j) = j-th triangle of leaf slot s
-  uint32_t w = 0;
-  for (int bit = 0; bit < 24; ++bit) {
-    if (!(nd.tmask & (1u << bit))) continue;
-    const int s = bit & 7, k = bit >> 3;
-    const uint32_t p = T.sorted[first_prim(T, ch[child_in_slot[s]]) + (uint32_t)k];
-    const float* t = abc + 9 * (size_t)p;
-    TriRec R;
-    R.v0x = t[0]; R.v0y = t[1]; R.v0z = t[2];
-    R.e0x = t[3] - t[0]; R.e0y = t[4] - t[1]; R.e0z = t[5] - t[2];  // e0 = b - a, e1 = c - a (accel/triangle.hpp:48-50)
-    R.e1x = t[6] - t[0]; R.e1y = t[7] - t[1]; R.e1z = t[8] - t[2];
-    R.prim = p; R.material = prim_material[p]; R.pad1 = 0;
-    tris[nd.tri_base + w++] = R;
+  node_origin_encode(nd, gi[0], gi[1], gi[2], valid);
+  nd.child_base = atomicAdd(&counters[0], n_inner + n_tri);
+  if (n_tri) atomicAdd(&counters[1], n_tri);
+  if (n_inner) atomicAdd(&counters[3], n_inner);
+  const uint32_t qpos = n_inner ? atomicAdd(&counters[2], n_inner) : 0u;
+  // the children's pool elements, in slot order: triangle records now, nodelets by the next level's threads
+  uint32_t rank = 0, r = 0;
+  for (int s = 0; s < 8; ++s) {
+    const int i = child_in_slot[s];
+    if (i < 0) continue;
+    const uint32_t ei = nd.child_base + rank++;
+    if (nd.imask & (1u << s)) { qa_out[qpos + r] = ch[i]; qb_out[qpos + r] = ei; ++r; }
+    else {
+      const uint32_t p = T.sorted[first_prim(T, ch[i])];
+      const float* t = abc + 9 * (size_t)p;
+      TriRec R;
+      R.v0x = t[0]; R.v0y = t[1]; R.v0z = t[2];
+      R.e0x = t[3] - t[0]; R.e0y = t[4] - t[1]; R.e0z = t[5] - t[2];  // e0 = b - a, e1 = c - a (accel/triangle.hpp:48-50)
+      R.e1x = t[6] - t[0]; R.e1y = t[7] - t[1]; R.e1z = t[8] - t[2];
+      R.prim = p; R.material = prim_material[p]; R.pad1 = 0; R.pad2[0] = R.pad2[1] = R.pad2[2] = R.pad2[3] = 0;
+      pool[ei].tri = R;
+    }
   }
-  nodes[n8] = nd;
-  if (n_inner) {
-    const uint32_t qpos = atomicAdd(&counters[2], n_inner);
-    uint32_t r = 0;
-    for (int s = 0; s < 8; ++s)
-      if (nd.imask & (1u << s)) { qa_out[qpos + r] = ch[child_in_slot[s]]; qb_out[qpos + r] = nd.child_base + r; ++r; }
-  }
+  pool[n8].node = nd;
 }
 
 #define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::snprintf(err, errlen, "%s: %s", #x, hipGetErrorString(e_)); cleanup(); return 1; } } while (0)
@@ -264,14 +271,14 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, const float* __restric
 }  // namespace
 
 int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen) {
-  out->nodes = nullptr; out->tris = nullptr; out->num_nodes = 0; out->num_tris = 0; out->depth = 1;
+  std::memset(out, 0, sizeof(*out)); out->depth = 1;
   void* bufs[16]; int nb = 0;
-  Node8* nodes = nullptr; TriRec* tris = nullptr;  // the outputs: freed by cleanup() unless the build succeeds
-  bool keep_outputs = false;
+  PoolElem* pool = nullptr;  // the output: freed by cleanup() unless the build succeeds
+  bool keep_output = false;
   auto cleanup = [&]() {
     for (int i = 0; i < nb; ++i) (void)hipFree(bufs[i]);
     nb = 0;
-    if (!keep_outputs) { if (nodes) (void)hipFree(nodes); if (tris) (void)hipFree(tris); nodes = nullptr; tris = nullptr; }
+    if (!keep_output && pool) { (void)hipFree(pool); pool = nullptr; }
   };
   auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; bufs[nb++] = p; return p; };
   if (n < 2) { std::snprintf(err, errlen, "device builder needs at least 2 triangles"); return 1; }
@@ -288,7 +295,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   if (!pbox || !cb || !keys || !keys2 || !vals || !sorted || !left || !right || !parent || !first || !last || !flags || !nbox || !queues || !counters) {
     std::snprintf(err, errlen, "hipMalloc failed in the device BVH builder"); cleanup(); return 1;
   }
-  const uint32_t init_cb[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  const uint32_t init_cb[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   HCHK(hipMemcpyAsync(cb, init_cb, sizeof(init_cb), hipMemcpyHostToDevice, stream));
   const dim3 g((n + GB - 1) / GB), b(GB);
   hipLaunchKernelGGL(k_prim_bounds, g, b, 0, stream, d_abc, n, pbox, cb);
@@ -302,25 +309,31 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));
   hipLaunchKernelGGL(k_fit, g, b, 0, stream, pbox, sorted, (int)n, left, right, parent, flags, nbox);
   HCHK(hipGetLastError());
+  // the scene grid of the nodelets' origins: from the bounds of the geometry
+  uint32_t h_cb[12];
+  HCHK(hipMemcpyAsync(h_cb, cb, sizeof(h_cb), hipMemcpyDeviceToHost, stream));
+  HCHK(hipStreamSynchronize(stream));
+  float glo[3], ghi[3];
+  for (int a = 0; a < 3; ++a) { glo[a] = ord2f(h_cb[6 + a]); ghi[a] = ord2f(h_cb[9 + a]); }
+  const SceneGrid grid = make_scene_grid(glo, ghi);
 
-  // outputs: at most n-1 inner BVH2 nodes can become Node8s (+1), exactly n triangle records
-  if (hipMalloc((void**)&nodes, sizeof(Node8) * (size_t)n) != hipSuccess || hipMalloc((void**)&tris, sizeof(TriRec) * (size_t)n) != hipSuccess) {
-    std::snprintf(err, errlen, "hipMalloc failed (BVH8 arrays)"); cleanup(); return 1;
+  // output pool: n triangle records + at most n - 1 nodelets (every nodelet has at least two children)
+  if (hipMalloc((void**)&pool, sizeof(PoolElem) * 2 * (size_t)n) != hipSuccess) {
+    pool = nullptr;
+    std::snprintf(err, errlen, "hipMalloc failed (BVH8 pool)"); cleanup(); return 1;
   }
   uint32_t* qa[2] = {queues, queues + 2 * (size_t)n}; uint32_t* qb[2] = {queues + (size_t)n, queues + 3 * (size_t)n};
   const uint32_t zero_root[2] = {0u, 0u};
   HCHK(hipMemcpyAsync(qa[0], &zero_root[0], 4, hipMemcpyHostToDevice, stream));
   HCHK(hipMemcpyAsync(qb[0], &zero_root[1], 4, hipMemcpyHostToDevice, stream));
-  uint32_t h_counters[3] = {1u, 0u, 0u};  // node 0 is the root
+  uint32_t h_counters[4] = {1u, 0u, 0u, 1u};  // element 0 is the root nodelet
   HCHK(hipMemcpyAsync(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
   Tree2 T{left, right, first, last, nbox, sorted, (int)n};
-  uint32_t leaf_max = 1;  // measured on Soup(100k): 1-triangle leaf slots trace 23% faster than 3 (profiles/README.md)
-  if (const char* e = getenv("PHX_LBVH_LEAF")) leaf_max = (uint32_t)std::max(1, std::min(3, atoi(e)));
   uint32_t count = 1, depth = 0; int cur = 0;
   while (count > 0) {
     ++depth;
-    hipLaunchKernelGGL(k_collapse, dim3((count + 63) / 64), dim3(64), 0, stream, T, d_abc, d_prim_material, qa[cur], qb[cur], count, qa[cur ^ 1], qb[cur ^ 1],
-                       counters, nodes, tris, leaf_max);
+    hipLaunchKernelGGL(k_collapse, dim3((count + 63) / 64), dim3(64), 0, stream, T, grid, d_abc, d_prim_material, qa[cur], qb[cur], count, qa[cur ^ 1], qb[cur ^ 1],
+                       counters, pool);
     HCHK(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
     HCHK(hipStreamSynchronize(stream));
     count = h_counters[2];
@@ -334,8 +347,8 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   }
   HCHK(hipStreamSynchronize(stream));
   if (h_counters[1] != n) { std::snprintf(err, errlen, "device BVH builder lost triangles (%u of %u)", h_counters[1], n); cleanup(); return 1; }
-  keep_outputs = true;
-  out->nodes = nodes; out->tris = tris; out->num_nodes = h_counters[0]; out->num_tris = h_counters[1]; out->depth = depth;
+  keep_output = true;
+  out->pool = pool; out->num_elems = h_counters[0]; out->num_tris = h_counters[1]; out->num_nodes = h_counters[3]; out->depth = depth; out->grid = grid;
   cleanup();
   return 0;
 }

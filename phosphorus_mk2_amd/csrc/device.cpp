@@ -72,7 +72,7 @@ struct phx_device {
   bool preprocessed = false;
 
   // scene
-  DevBuf<Node8> d_nodes; DevBuf<TriRec> d_tris; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals;
+  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals;
   DevBuf<DevMaterial> d_materials; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
   DevScene scene{};
   uint32_t num_materials = 0;
@@ -305,24 +305,25 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   int rc;
   if ((rc = d->d_prim_material.upload(prim_material))) return rc;
   const auto t_bvh0 = std::chrono::steady_clock::now();
-  uint32_t bvh_depth = 0; size_t bvh_node_count = 0;
-  if (d->opt.bvh_builder == PHX_BVH_DEVICE_LBVH) {
+  uint32_t bvh_depth = 0; size_t bvh_node_count = 0, bvh_elems = 0;
+  SceneGrid bvh_grid{};
+  uint32_t builder = d->opt.bvh_builder;
+  if (builder == PHX_BVH_AUTO) builder = prim_material.size() > 2000000u ? PHX_BVH_DEVICE_LBVH : PHX_BVH_HOST_SAH;
+  if (builder == PHX_BVH_DEVICE_LBVH) {
     // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
     DevBuf<float> d_abc;
     if ((rc = d_abc.upload(abc))) return rc;
     GpuBvh g{}; char msg[256] = {0};
     if (build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, (uint32_t)prim_material.size(), &g, msg, sizeof(msg)))
       return fail(PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
-    d->d_nodes.adopt(g.nodes, g.num_nodes); d->d_tris.adopt(g.tris, g.num_tris);
-    bvh_depth = g.depth; bvh_node_count = g.num_nodes;
-  } else if (d->opt.bvh_builder == PHX_BVH_HOST_SAH) {
+    d->d_pool.adopt(g.pool, g.num_elems);
+    bvh_depth = g.depth; bvh_node_count = g.num_nodes; bvh_elems = g.num_elems; bvh_grid = g.grid;
+  } else if (builder == PHX_BVH_HOST_SAH) {
     Bvh8 bvh;
     const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads);
-    for (auto& T : bvh.tris) T.material = prim_material[T.prim];
-    if ((rc = d->d_nodes.upload(bvh.nodes))) return rc;
-    if ((rc = d->d_tris.upload(bvh.tris))) return rc;
-    bvh_depth = bvh.depth; bvh_node_count = bvh.nodes.size();
+    build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads, prim_material.data());
+    if ((rc = d->d_pool.upload(bvh.pool))) return rc;
+    bvh_depth = bvh.depth; bvh_node_count = bvh.num_nodes; bvh_elems = bvh.pool.size(); bvh_grid = bvh.grid;
   } else {
     return fail(PHX_ERR_ARG, "unknown bvh_builder");
   }
@@ -336,8 +337,9 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if ((rc = d->d_light_tris.upload(light_tris))) return rc;
 
   DevScene& sc = d->scene;
-  sc.nodes = reinterpret_cast<const uint32_t*>(d->d_nodes.p);
-  sc.tris = d->d_tris.p;
+  sc.pool = reinterpret_cast<const uint32_t*>(d->d_pool.p);
+  sc.tris = reinterpret_cast<const TriRec*>(d->d_pool.p);
+  sc.grid = bvh_grid;
   sc.prim_material = d->d_prim_material.p;
   sc.prim_normals = any_smooth ? d->d_prim_normals.p : nullptr;
   sc.materials = d->d_materials.p;
@@ -350,7 +352,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   sc.width = s->camera.film_width; sc.height = s->camera.film_height;
   sc.max_depth = d->opt.path_depth;
   sc.stack_levels = bvh_depth;
-  sc.num_nodes = (uint32_t)bvh_node_count;
+  sc.num_elems = (uint32_t)bvh_elems;
   {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, d->hip_device));
     sc.num_cus = (uint32_t)prop.multiProcessorCount;
@@ -359,7 +361,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   for (auto& m : mats) for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0;
   d->num_materials = s->num_materials;
   d->bvh_nodes = bvh_node_count;
-  d->bvh_bytes = bvh_node_count * sizeof(Node8) + prim_material.size() * sizeof(TriRec);
+  d->bvh_bytes = bvh_elems * sizeof(PoolElem);
   d->bvh_build_ms = std::chrono::duration<double, std::milli>(t_bvh1 - t_bvh0).count();
   d->preprocess_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pre0).count();
   d->num_triangles = prim_material.size();
@@ -584,6 +586,9 @@ int phx_device::run_frame() {
   HIPCHK(hipMemcpy(&ds, dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
   stats.camera_samples = ds.camera_samples; stats.rays_closest = ds.rays_closest; stats.rays_shadow = ds.rays_shadow;
   stats.rays_masked = ds.rays_closest - ds.rays_shadow;  // every shaded slot is a shadow ray or a masked slot (spt.hpp:138-141)
+  for (int k = 0; k < 2; ++k) { stats.node_visits_lds[k] = ds.node_visits_lds[k]; stats.node_visits_mem[k] = ds.node_visits_mem[k]; stats.tri_tests[k] = ds.tri_tests[k]; }
+  stats.instrumented = launch_counts_traversal_work() ? 1 : 0;
+  stats.wave_iters = ds.wave_iters; stats.node_block_execs = ds.node_block_execs; stats.tri_block_execs = ds.tri_block_execs; stats.refills = ds.refills;
   for (auto& te : timed) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));

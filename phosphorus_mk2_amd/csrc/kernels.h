@@ -23,8 +23,9 @@ struct DevLight { uint32_t first_tri, num_tris; float area; uint32_t material; }
 struct DevLightTri { float ax, ay, az, bx, by, bz, cx, cy, cz; uint32_t prim; uint32_t mesh_mat; uint32_t face; };
 
 struct DevScene {
-  const uint32_t* nodes;          // Node8 as 20 words each
-  const TriRec* tris;
+  const uint32_t* pool;           // the BVH8 pool: 16 words per element, element 0 = root nodelet (bvh8.h)
+  const TriRec* tris;             // the same pool seen as triangle records (hit records carry pool indices)
+  SceneGrid grid;                 // grid of the nodelets' origins
   const uint32_t* prim_material;  // per primitive (scene_t::triangles() order): material | smooth << 31
   const float* prim_normals;      // 9 floats per primitive (n0,n1,n2) or nullptr when no face is smooth
   const DevMaterial* materials;
@@ -37,14 +38,20 @@ struct DevScene {
   uint32_t width, height;
   uint32_t max_depth;
   uint32_t stack_levels;          // BVH depth
-  uint32_t num_nodes;             // Node8 count (nodes are stored breadth-first)
+  uint32_t num_elems;             // pool elements (stored breadth first: a prefix of the pool is the top of the tree)
   uint32_t num_cus;               // compute units of the device (persistent grid sizing)
   uint32_t diffuse_only;          // every lobe of every material is Lambert: k_shade<true>
 };
 
 // counters: [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity)
 enum { CNT_SHADOW = 2, CNT_CURSOR = 4, CNT_WORDS = 8 };
-struct DevStats { unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples; };
+struct DevStats {
+  unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples;
+  // instrumented build only (-DPHX_COUNT=1, `make variant NAME=count`): traversal work, [0] closest-hit rays, [1] shadow rays
+  unsigned long long node_visits_lds[2], node_visits_mem[2], tri_tests[2];
+  // wave-level: loop iterations, executions of the node block / the triangle block (a block runs when ANY lane needs it)
+  unsigned long long wave_iters, node_block_execs, tri_block_execs, refills;
+};
 
 struct PassBuffers {
   float4* ro[2]; float4* rd[2];
@@ -69,6 +76,8 @@ struct TracePlan { uint32_t block, ntop, levels, lds_bytes, wg_per_cu; };
 TracePlan trace_plan(const DevScene& sc);
 // per device, once: lets the traversal kernels use the CU's full 160 KB of LDS as dynamic shared memory
 hipError_t init_kernels_on_current_device();
+
+bool launch_counts_traversal_work();  // true in the instrumented build (PHX_COUNT)
 
 // launches (all asynchronous on `stream`)
 // start of a pass: queue 0 stands for the num_pixels x num_samples camera rays, which are rebuilt on the fly (camera_ray)

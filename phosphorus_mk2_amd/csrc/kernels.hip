@@ -18,6 +18,12 @@
 namespace phx {
 
 #define PHX_BLOCK 256
+#ifndef PHX_PERM_LUT
+#define PHX_PERM_LUT 1  /* 1: the octant permutations of the hit masks come from a 2 KB table in LDS instead of 2 x 15 VALU instructions */
+#endif
+#ifndef PHX_COUNT
+#define PHX_COUNT 0  /* 1: instrumented build that counts node visits and triangle tests (bench.py's device-layout byte model) */
+#endif
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
@@ -107,21 +113,28 @@ template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of thi
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
                                              uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t refill_min,
                                              const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0,
-                                             const DynQueue dq) {
+                                             const DynQueue dq, const uint8_t* __restrict__ perm_lut) {
   const uint32_t lane = __lane_id();
   bool active = false, any = false;
   uint32_t phase = 0;  // wave-uniform: 0 = shadow range, 1 = closest range, 2 = drained
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
   float tbest = 0.f, hu = 0.f, hv = 0.f;
-  uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, tb = 0, th = 0, tm = 0, path = 0;
+  uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, th = 0, path = 0;
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
   uint32_t dlo = 0, dhi = 0, dfirst = 3u;  // DYN: the wave's current chunk [dlo, dhi) and "first chunk not yet taken" bits
+#if PHX_COUNT
+  uint32_t cnt_lds[2] = {0, 0}, cnt_mem[2] = {0, 0}, cnt_tri[2] = {0, 0};  // instrumented build: this lane's traversal work
+  uint32_t cnt_iter = 0, cnt_nb = 0, cnt_tb = 0, cnt_refill = 0;              // ... and the wave's (wave-uniform)
+#endif
   for (;;) {
     // ---- refill idle lanes from the workgroup's cursors
     const unsigned long long idle = __ballot(!active);
     if (phase < 2u && (uint32_t)__popcll(idle) >= refill_min) {
+#if PHX_COUNT
+      ++cnt_refill;
+#endif
       const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
       uint32_t hi, base;
       if (DYN) {
@@ -166,7 +179,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             tbest = b.w; path = f2u(a.w);
           }
           hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
-          ng_base = 0; ng_hits = 0x80000000u; tb = 0; th = 0; sp = 0;
+          ng_base = 0; ng_hits = 0x80000000u; th = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
           any = phase == 0u;
           active = true;
         }
@@ -175,6 +188,10 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       if (phase < 2u && __ballot(active) == 0ull) continue;  // nothing in flight yet: go fetch from the next range
     }
     if (!__ballot(active)) break;
+#if PHX_COUNT
+    ++cnt_iter;
+    if (__ballot(active && th == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
+#endif
 #pragma unroll
     for (int step = 0; step < PHX_STEPS_PER_REFILL; ++step)
     if (active) {
@@ -185,29 +202,46 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         if (rest > 0x00ffffffu) { stack_base[sp * BLOCK] = make_uint2(ng_base, rest); ++sp; }
         const uint32_t slot = (bit - 24u) ^ r.oct_inv;
         const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
-        uint32_t w[20];
-        if (ni < ntop) {  // top-of-tree nodelet staged in LDS: five ds_read_b128 instead of five L1 requests per lane
+        uint32_t w[16];
+#if PHX_COUNT
+        if (ni < ntop) ++cnt_lds[any ? 1 : 0]; else ++cnt_mem[any ? 1 : 0];
+#endif
+        if (ni < ntop) {  // top-of-tree nodelet staged in LDS: four ds_read_b128 instead of four L1 requests per lane
           const uint4* s4 = top + ni * (PHX_NODE_LDS_BYTES / 16u);
 #pragma unroll
-          for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+          for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
         } else {
-          const uint4* s4 = reinterpret_cast<const uint4*>(sc.nodes + (size_t)ni * 20u);
+          const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ni * 4u;
 #pragma unroll
-          for (int k = 0; k < 5; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+          for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
         }
-        const uint32_t hm = node_hitmask(w, r, tbest);
-        ng_base = w[4];
-        ng_hits = (hm & 0xff000000u) | (w[3] >> 24);
-        tb = w[5]; tm = w[6];
-        th = hm & 0x00ffffffu;
+#if PHX_PERM_LUT
+        const uint32_t hm = node_hitmask(w, sc.grid, r, tbest, [&](uint32_t m) { return (uint32_t)perm_lut[(r.oct_inv << 8) | m]; });
+#else
+        const uint32_t hm = node_hitmask(w, sc.grid, r, tbest);
+#endif
+        ng_base = w[3];                // the children of the node just visited: nodelets and triangle records, in slot order
+        ng_hits = hm & 0xff0000ffu;    // pending inner children | valid mask
+        th = (hm >> 16) & 0xffu;       // pending triangles, by slot
       }
-      // ---- one triangle test
+      // ---- one triangle test (ng_base / the valid byte of ng_hits still belong to the node whose triangles are pending)
+#if PHX_COUNT
+      if (th != 0 && lane == (uint32_t)__ffsll((long long)__ballot(th != 0)) - 1u) ++cnt_tb;
+#endif
       if (th != 0) {
         const uint32_t k = 31u - (uint32_t)__clz((int)th);
         th &= ~(1u << k);
-        const uint32_t ti = tb + (uint32_t)__popc(tm & ~(0xffffffffu << k));
-        const TriRec T = sc.tris[ti];
+        const uint32_t ti = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << k));
+        const uint4* t4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ti * 4u;
+        const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2];  // three of the record's four words: v0, e0, e1, prim
+        TriRec T;
+        T.v0x = u2f(t0.x); T.v0y = u2f(t0.y); T.v0z = u2f(t0.z); T.e0x = u2f(t0.w);
+        T.e0y = u2f(t1.x); T.e0z = u2f(t1.y); T.e1x = u2f(t1.z); T.e1y = u2f(t1.w);
+        T.e1z = u2f(t2.x); T.prim = t2.y;
         float us, vs, ds;
+#if PHX_COUNT
+        ++cnt_tri[any ? 1 : 0];
+#endif
         if (mt_intersect(T, r.o, r.d, tbest, hprim, us, vs, ds)) {
           tbest = ds; hu = us; hv = vs; htri = ti; hprim = T.prim;
           if (any) active = false;  // occluded: nothing to add
@@ -233,6 +267,19 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       }
     }
   }
+#if PHX_COUNT
+  for (int k = 0; k < 2; ++k) {
+    atomicAdd(&pb.stats->node_visits_lds[k], (unsigned long long)cnt_lds[k]);
+    atomicAdd(&pb.stats->node_visits_mem[k], (unsigned long long)cnt_mem[k]);
+    atomicAdd(&pb.stats->tri_tests[k], (unsigned long long)cnt_tri[k]);
+  }
+  if (cnt_tb) atomicAdd(&pb.stats->tri_block_execs, (unsigned long long)cnt_tb);  // counted by the first lane that had a triangle
+  if (lane == 0) {
+    atomicAdd(&pb.stats->wave_iters, (unsigned long long)cnt_iter);
+    atomicAdd(&pb.stats->node_block_execs, (unsigned long long)cnt_nb);
+    atomicAdd(&pb.stats->refills, (unsigned long long)cnt_refill);
+  }
+#endif
 }
 
 // Trace kernel: closest-hit rays of ray queue `q` (if do_closest) and any-hit rays of the shadow queue `sq`
@@ -245,7 +292,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 //   !DYN: the grid is a fixed multiple of the resident workgroups and every workgroup owns one contiguous range of each
 //   queue, refilled through an LDS cursor.  The split is XCD-aware: workgroups b, b+8, ... share an XCD and its L2, so
 //   each XCD gets a contiguous eighth of the queue.
-// Dynamic LDS layout: [ntop nodelets x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
+// Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
 template <int BLOCK, bool GEN, bool DYN>
 __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
                                                  int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t gmul, uint32_t target_chunks) {
@@ -253,6 +300,7 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
   uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
+  uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 4);  // PHX_PERM_LUT: 8 octants x 256 masks
   const uint32_t n_closest = do_closest ? pb.counters[q] : 0u;
   const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq] : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -302,12 +350,16 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
     range(n_closest, clo, chi);
     if (shi <= slo && chi <= clo) return;  // nothing for this workgroup (uniform)
   }
-  // stage the top of the tree (nodes are stored breadth-first: the first ntop nodes ARE the top levels)
-  const uint4* g4 = reinterpret_cast<const uint4*>(sc.nodes);
-  for (uint32_t i = threadIdx.x; i < ntop * 5u; i += BLOCK) top[i] = g4[i];
+  // stage the top of the tree (the pool is stored breadth first: its first ntop elements ARE the top levels); a staged element
+  // keeps an 80-byte stride in LDS (PHX_NODE_LDS_BYTES, bvh8.h)
+  const uint4* g4 = reinterpret_cast<const uint4*>(sc.pool);
+  for (uint32_t i = threadIdx.x; i < ntop * 4u; i += BLOCK) top[(i >> 2) * (PHX_NODE_LDS_BYTES / 16u) + (i & 3u)] = g4[i];
   if (threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
+#if PHX_PERM_LUT
+  for (uint32_t i = threadIdx.x; i < 2048u; i += BLOCK) perm_lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
+#endif
   __syncthreads();
-  trace_stream<BLOCK, GEN, DYN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0, dq);
+  trace_stream<BLOCK, GEN, DYN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0, dq, perm_lut);
 }
 
 // stage-level hook (phx_dev_trace): one ray per lane run to completion with the plain traverse8 loop of bvh8.h.  The per-lane
@@ -320,7 +372,7 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_trace_rays(DevScene sc, uint32_t 
   const float4 a = ro[i], b = rd[i];
   LdsStack<0> st{ray_stack + threadIdx.x, 0};
   Hit h;
-  traverse8<ANY>(sc.nodes, sc.tris, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
+  traverse8<ANY>(sc.pool, sc.grid, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
   hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri == 0xffffffffu ? 0xffffffffu : sc.tris[h.tri].prim));  // primitive in scene_t::triangles() order
 }
 
@@ -615,6 +667,8 @@ void for_each_trace_kernel(F&& f) {
 }
 }  // namespace
 
+bool launch_counts_traversal_work() { return PHX_COUNT != 0; }
+
 // Allow every traversal kernel the CU's full 160 KB of LDS as dynamic shared memory ON THE CURRENT DEVICE.  The attribute is
 // per device and per kernel, so the host calls this once for each phx_device it makes (device.cpp: phx_dev_make).
 hipError_t init_kernels_on_current_device() {
@@ -638,11 +692,11 @@ TracePlan trace_plan(const DevScene& sc) {
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
     uint32_t ntop_req = E.ntop_env;
     if (!ntop_req) {
-      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.levels * blk * 8u + 16u;
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.levels * blk * 8u + 16u + (PHX_PERM_LUT ? 2048u : 0u);
       ntop_req = share > stacks + 9u * PHX_NODE_LDS_BYTES ? (share - stacks) / PHX_NODE_LDS_BYTES : 9u;
     }
-    ntop_out = std::min(ntop_req, sc.num_nodes);
-    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.levels * blk * 8u + 16u;
+    ntop_out = std::min(ntop_req, sc.num_elems);
+    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.levels * blk * 8u + 16u + (PHX_PERM_LUT ? 2048u : 0u);
     return std::min(160u * 1024u / lds_out, 2048u / blk);
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone

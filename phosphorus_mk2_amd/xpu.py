@@ -23,7 +23,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphx_hip.so")
+# PHX_LIB selects another build of the same library (A/B experiments: scripts/ab.sh builds variants with extra -D flags)
+LIB_PATH = os.environ.get("PHX_LIB") or os.path.join(_HERE, "libphx_hip.so")
 _lib = None
 
 
@@ -53,7 +54,7 @@ class Options:
     """parsed_options_t (src/options.hpp:6-43) plus the device knobs."""
 
     def __init__(self, samples_per_pixel=16, paths_per_sample=16, path_depth=9, single_threaded=False, host_only=False,
-                 render_normals=False, verbose=False, device_ordinal=-1, samples_in_flight=0, tiles_per_batch=0, bvh_builder="host"):
+                 render_normals=False, verbose=False, device_ordinal=-1, samples_in_flight=0, tiles_per_batch=0, bvh_builder="auto"):
         self.samples_per_pixel = samples_per_pixel
         self.paths_per_sample = paths_per_sample
         self.path_depth = path_depth
@@ -64,7 +65,7 @@ class Options:
         self.device_ordinal = device_ordinal
         self.samples_in_flight = samples_in_flight
         self.tiles_per_batch = tiles_per_batch
-        self.bvh_builder = bvh_builder  # "host": binned SAH on the host cores; "device": LBVH built on the GPU
+        self.bvh_builder = bvh_builder  # "host": binned SAH on the host cores; "device": LBVH built on the GPU; "auto": by scene size
 
     def pack(self):
         o = abi.Options()
@@ -72,7 +73,7 @@ class Options:
         o.single_threaded, o.host_only = int(self.single_threaded), int(self.host_only)
         o.render_normals, o.verbose = int(self.render_normals), int(self.verbose)
         o.device_ordinal, o.samples_in_flight, o.tiles_per_batch = self.device_ordinal, self.samples_in_flight, self.tiles_per_batch
-        o.bvh_builder = {"host": abi.BVH_HOST_SAH, "device": abi.BVH_DEVICE_LBVH}[self.bvh_builder]
+        o.bvh_builder = {"auto": abi.BVH_AUTO, "host": abi.BVH_HOST_SAH, "device": abi.BVH_DEVICE_LBVH}[self.bvh_builder]
         return o
 
 
@@ -254,7 +255,13 @@ class HipDevice:
     def stats(self):
         st = abi.Stats()
         _check(self._lib, self._lib.phx_dev_get_stats(self._h, C.byref(st)), "phx_dev_get_stats")
-        return {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+        out = {}
+        for k, _ in st._fields_:
+            if k == "reserved":
+                continue
+            v = getattr(st, k)
+            out[k] = list(v) if hasattr(v, "__len__") else v
+        return out
 
     # ---- stage-level hooks (parity tests) -------------------------------------------------------
     def trace(self, o, d, tmax, shadow=False):
@@ -296,7 +303,7 @@ class HipDevice:
 
 
 def render(scene_desc, spp=16, pps=1, depth=9, seed=1, normals=False, tile_size=32, rank=0, world=1, callback_tiles=False,
-           samples_in_flight=0, tiles_per_batch=0, native_sink=False, bvh_builder="host"):
+           samples_in_flight=0, tiles_per_batch=0, native_sink=False, bvh_builder="auto"):
     """Convenience: the call sequence of session_t::render (plugins/blender/session.cpp:73-94):
     discover -> preprocess -> tiles_t::make -> start -> join.  Returns (film array HxWxC, stats)."""
     opts = Options(samples_per_pixel=spp, paths_per_sample=pps, path_depth=depth, samples_in_flight=samples_in_flight,

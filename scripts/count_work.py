@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Traversal work per ray from the instrumented build (libphx_hip_count.so: `make -C phosphorus_mk2_amd/csrc variant NAME=count
+EXTRA=-DPHX_COUNT=1`): node visits served from LDS / through the vector L1, triangle tests, and how full the wave's node and
+triangle blocks run.  python scripts/count_work.py [--triangles N --width W --height H --spp S --builder host|device]"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["PHX_LIB"] = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
+from phosphorus_mk2_amd import scenes, xpu  # noqa: E402
+p = argparse.ArgumentParser()
+p.add_argument("--triangles", type=int, default=100000); p.add_argument("--width", type=int, default=1280); p.add_argument("--height", type=int, default=720)
+p.add_argument("--spp", type=int, default=256); p.add_argument("--builder", default="auto")
+a = p.parse_args()
+sc = scenes.soup(a.triangles, width=a.width, height=a.height)
+film, st = xpu.render(sc, spp=a.spp, pps=1, depth=9, seed=1, native_sink=True, bvh_builder=a.builder)
+assert st["instrumented"] == 1
+out = {"triangles": a.triangles, "film": [a.width, a.height], "spp": a.spp, "builder": a.builder, "bvh_bytes": st["bvh_bytes"], "bvh_nodes": st["bvh_nodes"],
+       "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]}}
+for k, name in ((0, "closest"), (1, "shadow")):
+    rays = st["rays_closest"] if k == 0 else st["rays_shadow"]
+    out[name] = {"rays": rays, "node_visits_lds_per_ray": st["node_visits_lds"][k] / rays, "node_visits_mem_per_ray": st["node_visits_mem"][k] / rays,
+                 "tri_tests_per_ray": st["tri_tests"][k] / rays}
+rays = st["rays_closest"] + st["rays_shadow"]
+nv = sum(st["node_visits_lds"]) + sum(st["node_visits_mem"]); tt = sum(st["tri_tests"])
+out["wave"] = {"iterations": st["wave_iters"], "node_block_execs": st["node_block_execs"], "tri_block_execs": st["tri_block_execs"], "refills": st["refills"],
+               "lanes_per_node_block": nv / max(1, st["node_block_execs"]), "lanes_per_tri_block": tt / max(1, st["tri_block_execs"]),
+               "iterations_per_ray_x64": st["wave_iters"] * 64 / rays}
+print(json.dumps(out))

@@ -24,6 +24,7 @@ p.add_argument("--spp", type=int, default=16)
 p.add_argument("--world", type=int, default=1)
 p.add_argument("--rank", type=int, default=0)
 p.add_argument("--frames", type=int, default=2)
+p.add_argument("--builder", default="auto", choices=["auto", "host", "device"])
 a = p.parse_args()
 t0 = time.time()
 if a.scene == "soup":
@@ -33,7 +34,7 @@ elif a.scene == "zoo":
 else:
     sc = scenes.cornell(a.width, a.height)
 t_scene = time.time() - t0
-dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=a.spp, paths_per_sample=1, path_depth=9))[0]
+dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=a.spp, paths_per_sample=1, path_depth=9, bvh_builder=a.builder))[0]
 t0 = time.time()
 dev.preprocess(sc)
 t_pre = time.time() - t0
@@ -50,6 +51,6 @@ for _ in range(a.frames):
 rays = st["rays_closest"] + st["rays_shadow"]
 print(json.dumps({"scene": sc.name, "triangles": sc.num_triangles, "film": [a.width, a.height], "spp": a.spp, "rank": a.rank, "world": a.world,
                   "tiles": len(tiles), "scene_gen_s": t_scene, "preprocess_s": t_pre, "frame_s": best, "rays": rays, "Mrays_per_s": rays / best / 1e6,
-                  "trace_ms": st["trace_ms"], "shade_ms": st["shade_ms"], "bvh_MB": st["bvh_bytes"] / 1e6, "film_mean": float(film.data[..., :3].mean()),
+                  "builder": a.builder, "bvh_build_ms": st["bvh_build_ms"], "plan": [st["trace_block"], st["trace_ntop"], st["trace_levels"]], "trace_ms": st["trace_ms"], "shade_ms": st["shade_ms"], "bvh_MB": st["bvh_bytes"] / 1e6, "film_mean": float(film.data[..., :3].mean()),
                   "finite": bool(np.isfinite(film.data).all())}))
 dev.close()

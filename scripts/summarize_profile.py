@@ -29,16 +29,23 @@ stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
+# per k_trace launch: counters keyed by the launch's position among the k_trace dispatches of its pass (0 = camera rays, 1.. = bounces)
+per_launch = collections.defaultdict(lambda: collections.defaultdict(list))
 launches = collections.defaultdict(set)
 passes = collections.defaultdict(set)  # a counter collected in several passes is averaged over them
 mem = os.path.join(root, "gpurun_out", f"mem_{tag}")  # scripts/profile_mem.sh: TA / TCP / TD passes of the same command
 for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")) + glob.glob(os.path.join(mem, "*", "*", "*_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    trace_ids = sorted({int(r["Dispatch_Id"]) for r in rows if kname(r["Kernel_Name"]) == "k_trace"})
+    order = {d: i for i, d in enumerate(trace_ids)}
+    for r in rows:
         k = kname(r["Kernel_Name"])
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             passes[(k, r["Counter_Name"])].add(os.path.dirname(f))
             launches[k].add((os.path.dirname(f), r["Dispatch_Id"]))
+        if k == "k_trace":
+            per_launch[order[int(r["Dispatch_Id"])]][r["Counter_Name"]].append((os.path.dirname(f), float(r["Counter_Value"])))
 out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
        "kernels": {}}
 for (k, c), ps in passes.items():
@@ -66,5 +73,31 @@ for k, a in agg.items():
         if "SQ_WAIT_INST_ANY" in a and "SQ_WAVE_CYCLES" in a:
             e["wave_cycles_waiting_frac"] = a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"]
     out["kernels"][k] = e
+# k_trace launch by launch (a counter summed over its rows within a pass directory, averaged over the passes that collected it)
+pl = []
+for i in sorted(per_launch):
+    c = {}
+    for cn, vals in per_launch[i].items():
+        by_pass = collections.defaultdict(float)
+        for dpath, v in vals:
+            by_pass[dpath] += v
+        c[cn] = sum(by_pass.values()) / len(by_pass)
+    e = {"launch": i, "what": "camera rays" if i == 0 else f"bounce {i} closest-hit rays + bounce {i - 1} shadow rays", "counters": c}
+    if "GRBM_GUI_ACTIVE" in c:
+        cu_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c: e["l1_lane_accesses_per_clk_per_cu"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / cu_cycles
+        if "TA_TA_BUSY_sum" in c: e["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / cu_cycles
+        if "TD_TD_BUSY_sum" in c: e["td_busy_frac"] = c["TD_TD_BUSY_sum"] / cu_cycles
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c: e["hbm_bytes_corrected"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    if "TCC_HIT" in c: e["l2_hit_rate"] = c["TCC_HIT"] / (c["TCC_HIT"] + c["TCC_MISS"])
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_INSTS_VALU" in c: e["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
+    pl.append(e)
+out["k_trace_per_launch"] = pl
+# launch durations from the kernel trace of the --stats pass, in dispatch order
+kt = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+if kt:
+    rows = [r for r in csv.DictReader(open(kt[0])) if kname(r["Kernel_Name"]) == "k_trace"]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out["k_trace_launch_ms"] = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 json.dump(out, open(os.path.join(dst, f"{name}_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {x: v for x, v in e.items() if x != "counters"} for k, e in out["kernels"].items()}, indent=1))

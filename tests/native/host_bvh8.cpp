@@ -11,17 +11,18 @@ struct HostStack {
 };
 extern "C" {
 void* hb8_build(const float* tri_abc, uint32_t n, int threads) { Bvh8* b = new Bvh8(); build_bvh8(tri_abc, n, *b, threads); return b; }
+double hb8_cost(void* h, float cn, float ct) { return bvh8_sah_cost(*(Bvh8*)h, cn, ct); }
 void hb8_free(void* h) { delete (Bvh8*)h; }
-void hb8_info(void* h, uint64_t* out) { Bvh8* b = (Bvh8*)h; out[0] = b->nodes.size(); out[1] = b->tris.size(); out[2] = b->depth; }
+void hb8_info(void* h, uint64_t* out) { Bvh8* b = (Bvh8*)h; out[0] = b->num_nodes; out[1] = b->num_tris; out[2] = b->depth; }
 // returns max stack depth used
 int hb8_trace(void* h, uint32_t n, const float* o, const float* d, const float* tmax, int any, float* t, float* u, float* v, uint32_t* prim, uint64_t* counters) {
   Bvh8* b = (Bvh8*)h; int max_sp = 0; uint64_t nv = 0, tt = 0;
   for (uint32_t i = 0; i < n; ++i) {
     HostStack st; Hit hit; uint32_t a = 0, c = 0;
     v3 oo(o[3*i], o[3*i+1], o[3*i+2]), dd(d[3*i], d[3*i+1], d[3*i+2]);
-    if (any) traverse8<true>((const uint32_t*)b->nodes.data(), b->tris.data(), oo, dd, tmax[i], hit, st, &a, &c);
-    else traverse8<false>((const uint32_t*)b->nodes.data(), b->tris.data(), oo, dd, tmax[i], hit, st, &a, &c);
-    t[i] = hit.t; u[i] = hit.u; v[i] = hit.v; prim[i] = hit.tri == 0xffffffffu ? 0xffffffffu : b->tris[hit.tri].prim;
+    if (any) traverse8<true>((const uint32_t*)b->pool.data(), b->grid, oo, dd, tmax[i], hit, st, &a, &c);
+    else traverse8<false>((const uint32_t*)b->pool.data(), b->grid, oo, dd, tmax[i], hit, st, &a, &c);
+    t[i] = hit.t; u[i] = hit.u; v[i] = hit.v; prim[i] = hit.tri == 0xffffffffu ? 0xffffffffu : b->pool[hit.tri].tri.prim;
     if (st.max_sp > max_sp) max_sp = st.max_sp; nv += a; tt += c;
   }
   if (counters) { counters[0] = nv; counters[1] = tt; }
