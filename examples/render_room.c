@@ -3,6 +3,10 @@
  * Python, no C++ and no torch in the process.  Renders a small room (floor, back wall, emissive ceiling panel, two
  * tilted triangles) and writes the raw fp32 film (H x W x 4) to argv[1].
  *   make -C examples
+ *   ./render_room film.f32 [host-bvh|device-bvh|auto-bvh] [N]
+ * With N > 1 it is the reference's multi-device mechanism (src/core.cpp:103-115): N devices — one per GPU that phx_discover
+ * reports, wrapping around when the box has fewer — are all started on ONE tile queue and ONE film, and joined in turn.
+ * No collective: whoever renders a tile writes it into the shared film.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,25 +63,41 @@ int main(int argc, char** argv) {
   memset(&opt, 0, sizeof(opt));
   opt.samples_per_pixel = 8; opt.paths_per_sample = 1; opt.path_depth = 5; opt.device_ordinal = -1;
   if (argc > 2 && strcmp(argv[2], "device-bvh") == 0) opt.bvh_builder = PHX_BVH_DEVICE_LBVH;
+  if (argc > 2 && strcmp(argv[2], "host-bvh") == 0) opt.bvh_builder = PHX_BVH_HOST_SAH;
 
   int n = 0;
   if (phx_discover(&opt, &n) != PHX_OK || n < 1) return fail("phx_discover");
-  phx_device* dev = phx_dev_make(&opt);
-  if (!dev) return fail("phx_dev_make");
-  if (phx_dev_preprocess(dev, &scene) != PHX_OK) return fail("phx_dev_preprocess");
+  int num_devices = argc > 3 ? atoi(argv[3]) : 1;
+  if (num_devices < 1 || num_devices > 64) num_devices = 1;
+  phx_device* devs[64];
+  for (int i = 0; i < num_devices; ++i) { /* xpu_t::discover: one device object per GPU (src/xpu.cpp:7-9) */
+    opt.device_ordinal = num_devices > 1 ? i % n : -1;
+    devs[i] = phx_dev_make(&opt);
+    if (!devs[i]) return fail("phx_dev_make");
+    if (phx_dev_preprocess(devs[i], &scene) != PHX_OK) return fail("phx_dev_preprocess"); /* every device holds its own copy + BVH */
+  }
 
   float* film = (float*)calloc((size_t)W * H * 4, sizeof(float));
-  phx_tiles* tiles = phx_tiles_make(W, H, 32, 0, 1);
+  phx_tiles* tiles = phx_tiles_make(W, H, 32, 0, 1); /* ONE job::tiles_t for all devices */
   phx_frame frame;
   memset(&frame, 0, sizeof(frame));
   frame.tiles_user = tiles; frame.next_tile = phx_tiles_next;
   frame.sampler_seed = 7; frame.primary_components = 4;
-  frame.host_film = film;
-  if (phx_dev_start(dev, &frame) != PHX_OK) return fail("phx_dev_start");
-  if (phx_dev_join(dev) != PHX_OK) return fail("phx_dev_join");
+  frame.host_film = film;                             /* ONE film: tiles are disjoint, so no lock and no reduce */
+  for (int i = 0; i < num_devices; ++i)
+    if (phx_dev_start(devs[i], &frame) != PHX_OK) return fail("phx_dev_start");
+  for (int i = 0; i < num_devices; ++i)
+    if (phx_dev_join(devs[i]) != PHX_OK) return fail("phx_dev_join");
 
-  phx_stats st;
-  phx_dev_get_stats(dev, &st);
+  phx_stats st, sum;
+  memset(&sum, 0, sizeof(sum));
+  for (int i = 0; i < num_devices; ++i) {
+    phx_dev_get_stats(devs[i], &st);
+    sum.tiles += st.tiles; sum.camera_samples += st.camera_samples; sum.rays_closest += st.rays_closest; sum.rays_shadow += st.rays_shadow;
+    sum.bvh_nodes = st.bvh_nodes;
+    if (num_devices > 1) printf("device %d (GPU %d): tiles %llu\n", i, i % n, (unsigned long long)st.tiles);
+  }
+  st = sum;
   printf("tiles %llu camera_samples %llu rays %llu+%llu bvh_nodes %llu\n", (unsigned long long)st.tiles, (unsigned long long)st.camera_samples,
          (unsigned long long)st.rays_closest, (unsigned long long)st.rays_shadow, (unsigned long long)st.bvh_nodes);
   if (argc > 1) {
@@ -86,7 +106,7 @@ int main(int argc, char** argv) {
     fclose(f);
   }
   phx_tiles_free(tiles);
-  phx_dev_destroy(dev);
+  for (int i = 0; i < num_devices; ++i) phx_dev_destroy(devs[i]);
   free(film);
   return 0;
 }

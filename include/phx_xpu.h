@@ -82,8 +82,19 @@ typedef struct phx_lobe {
   float    yalpha;
   uint32_t refract;   /* Microfacet: 1 = transmissive */
   float    r;         /* Sheen roughness */
+  /* Per-hit closure weight — the one hit-dependent input the reference's own node shaders produce: a mix_closure_node whose `fac`
+   * is driven by fresnel_dielectric_node (Blender's glass node: plugins/blender/blender/shader.hpp:306-335,
+   * src/shaders/fresnel_dielectric_node.osl:16-20, mix_closure_node.osl:20).  At every hit
+   *   fac = fresnel_dielectric(dot(I, N), backfacing ? 1 / max(1e-5, fac_ior) : max(1e-5, fac_ior))      (src/shaders/fresnel.h)
+   * and the closure's weight is (pre_weight * term) * weight with term = fac (PHX_FAC_MIX_B) or 1 - fac (PHX_FAC_MIX_A), in the
+   * order material_t::eval_closure multiplies down the tree (src/material.cpp:218-305); a closure whose weight comes out all
+   * zero is not there at that hit (OSL: closure * 0 is the null closure).  PHX_FAC_NONE: weight is the whole constant weight. */
+  uint32_t fac_mode;
+  float    fac_ior;
+  float    pre_weight[3]; /* product of the constant weights ABOVE the hit-dependent factor in the closure tree */
   uint32_t pad;
 } phx_lobe;
+enum { PHX_FAC_NONE = 0, PHX_FAC_MIX_B = 1, PHX_FAC_MIX_A = 2 };
 
 typedef struct phx_material {
   uint32_t num_lobes;   /* 0 for pure emitters (diffuse_emitter_node.osl) */

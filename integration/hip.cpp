@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace {
-  phx_options to_options(const parsed_options_t& o) {
+  phx_options to_options(const parsed_options_t& o, int ordinal = -1) {
     phx_options out = {};
     out.samples_per_pixel = o.samples_per_pixel;
     out.paths_per_sample  = o.paths_per_sample;
@@ -22,7 +22,8 @@ namespace {
     out.single_threaded   = o.single_threaded;
     out.render_normals    = o.render_normals;
     out.verbose           = o.verbose;
-    out.device_ordinal    = -1;
+    out.host_only         = o.host_only;
+    out.device_ordinal    = ordinal;
     return out;
   }
 
@@ -35,7 +36,7 @@ namespace {
   }
 
   // phx_add_tile_fn  ->  film_t<>::add_tile: wrap the device's tile buffer in a render_buffer_t view
-  struct sink_t { film_t<>* film; render_buffer_t::descriptor_t format; };
+  typedef hip_t::sink_t sink_t;
   void add_tile(void* user, int32_t x, int32_t y, int32_t w, int32_t h, const float* data, uint32_t xstride, uint32_t ystride) {
     sink_t* sink = static_cast<sink_t*>(user);
     render_buffer_t view(sink->format);
@@ -45,21 +46,28 @@ namespace {
   }
 }
 
-hip_t::hip_t(const parsed_options_t& options) : device(nullptr), frame(nullptr) {
-  const phx_options o = to_options(options);
+hip_t::hip_t(const parsed_options_t& options, int ordinal) : device(nullptr), ordinal(ordinal) {
+  const phx_options o = to_options(options, ordinal);
   device = phx_dev_make(&o);
   if (!device) throw std::runtime_error(phx_last_error());
 }
 
 hip_t::~hip_t() { phx_dev_destroy(device); }
 
-hip_t* hip_t::make(const parsed_options_t& options) { return new hip_t(options); }
+hip_t* hip_t::make(const parsed_options_t& options, int ordinal) { return new hip_t(options, ordinal); }
+
+int hip_t::count(const parsed_options_t& options) {
+  const phx_options o = to_options(options);
+  int n = 0;
+  return phx_discover(&o, &n) == PHX_OK ? n : 0;
+}
 
 void hip_t::preprocess(const scene_t& scene) {
   // The closure recipe of a material is what material_t::evaluate would flatten for constant inputs
-  // (material.cpp:218-305).  `bake_closures` is the one piece the maintainer supplies: it runs each
-  // material's shader group once on a dummy ShaderGlobals and records the closure tree (ids = bsdf_t::type_t,
-  // weights, parameter structs) — see INTEGRATION.md §3.
+  // (material.cpp:218-305).  `bake_closures` is NOT defined anywhere in this repository: it is the one piece the
+  // maintainer supplies inside the reference tree, where OSL is available — run each material's shader group once on a
+  // neutral ShaderGlobals and record the closure tree (ids = bsdf_t::type_t, weights, parameter structs), INTEGRATION.md §3.
+  // Until it exists this binding is INCOMPLETE: it links only together with that function.
   extern void bake_closures(const material_t* m, phx_material* out);
 
   std::vector<phx_material> materials(scene.num_materials());
@@ -101,7 +109,6 @@ void hip_t::preprocess(const scene_t& scene) {
 }
 
 void hip_t::start(const scene_t&, frame_state_t& state) {
-  static thread_local sink_t sink;
   sink.film = state.film; sink.format = state.tiles->format;
   phx_frame f = {};
   f.tiles_user = state.tiles; f.next_tile = next_tile;

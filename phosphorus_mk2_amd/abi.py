@@ -11,6 +11,7 @@ LOBE_EMISSIVE, LOBE_DIFFUSE, LOBE_OREN_NAYAR, LOBE_REFLECTION = 0, 1, 2, 4
 LOBE_REFRACTION, LOBE_MICROFACET, LOBE_SHEEN, LOBE_BACKGROUND, LOBE_TRANSPARENT = 8, 16, 32, 64, 128
 BSDF_DIFFUSE, BSDF_GLOSSY, BSDF_SPECULAR, BSDF_REFLECT, BSDF_TRANSMIT = 1, 2, 4, 8, 16
 MAX_LOBES = 8
+FAC_NONE, FAC_MIX_B, FAC_MIX_A = 0, 1, 2
 BVH_AUTO, BVH_DEVICE_LBVH, BVH_HOST_SAH = 0, 1, 2
 MESH_UV_PER_VERTEX, MESH_NORMALS_PER_VERTEX = 1, 2
 
@@ -31,7 +32,8 @@ class Options(C.Structure):
 class Lobe(C.Structure):
     _fields_ = [
         ("type", C.c_uint32), ("weight", C.c_float * 3), ("alpha", C.c_float), ("eta", C.c_float),
-        ("xalpha", C.c_float), ("yalpha", C.c_float), ("refract", C.c_uint32), ("r", C.c_float), ("pad", C.c_uint32),
+        ("xalpha", C.c_float), ("yalpha", C.c_float), ("refract", C.c_uint32), ("r", C.c_float),
+        ("fac_mode", C.c_uint32), ("fac_ior", C.c_float), ("pre_weight", C.c_float * 3), ("pad", C.c_uint32),
     ]
 
 

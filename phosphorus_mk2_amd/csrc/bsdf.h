@@ -29,13 +29,17 @@ struct DevLobe {       // a lobe after add_lobe()/precompute() (src/bsdf.hpp:54-
   float xalpha, yalpha;
   uint32_t refract;
   float r;             // sheen roughness
+  uint32_t fac_mode;   // PHX_FAC_*: per-hit Fresnel mix factor on the weight (material_at_hit)
+  float fac_ior;
+  float px, py, pz;    // constant weights above the factor in the closure tree
 };
 struct DevMaterial {
   uint32_t num_lobes;
   uint32_t is_emitter;
   float ex, ey, ez;    // hits.e
   float sheen_L5;      // L(0.5, r) of the first sheen lobe of the material table (sheen.hpp:57 static)
-  uint32_t pad[2];
+  uint32_t per_hit;    // some lobe's weight depends on the hit (fac_mode != 0)
+  uint32_t pad;
   DevLobe lobes[8];
 };
 
@@ -85,6 +89,47 @@ PHX_HD float fresnel_dielectric(float cosi, float eta) {  // math/fresnel.hpp:6-
     return 0.5f * A * A * (1 + B * B);
   }
   return 1.0f;
+}
+
+// ---- per-hit closure weights -----------------------------------------------------------------------
+// What OSL would compute at this hit for the one hit-dependent input of the reference's node shaders: the mix factor of
+// Blender's glass node (plugins/blender/blender/shader.hpp:306-335).  fresnel_dielectric_node.osl:16-20 with the shader
+// globals of material_t::evaluate (src/material.cpp:425-436: I = hits.wi, N = n, backfacing = N.I < 0) and the OSL helper
+// src/shaders/fresnel.h:1-19 (NOT math/fresnel.hpp: no eta == 0 case, no inversion for cosi < 0); OSL floats are fp32.
+PHX_HD float osl_fresnel_dielectric(float cosi, float eta) {
+  const float c = fabsf(cosi);
+  float g = eta * eta - 1.0f + c * c;
+  if (g > 0.0f) {
+    g = sqrtf(g);
+    const float A = (g - c) / (g + c);
+    const float B = (c * (g + c) - 1.0f) / (c * (g - c) + 1.0f);
+    return 0.5f * A * A * (1.0f + B * B);
+  }
+  return 1.0f;
+}
+PHX_HD float fresnel_mix_factor(float ior, const v3& n, const v3& view /* hits.wi */) {
+  const float f = fmaxf(1.0e-5f, ior);
+  const bool backfacing = dot(n, view) < 0.0f;
+  const float eta = backfacing ? 1.0f / f : f;
+  return osl_fresnel_dielectric(dot(view, n), eta);
+}
+// The closure list of material `m` AT THIS HIT: weights resolved — (pre * term) * weight, the order eval_closure multiplies down
+// the tree — and closures whose weight is all zero dropped (OSL's null closure), so `out.num_lobes` is what bsdf_t::lobes
+// would be.  Only called for materials with per_hit set; the others use their baked table directly.
+PHX_HD void material_at_hit(const DevMaterial& m, const v3& n, const v3& view, DevMaterial& out) {
+  out.num_lobes = 0; out.is_emitter = m.is_emitter; out.ex = m.ex; out.ey = m.ey; out.ez = m.ez; out.sheen_L5 = m.sheen_L5;
+  out.per_hit = 0; out.pad = 0;
+  for (uint32_t i = 0; i < m.num_lobes; ++i) {
+    DevLobe l = m.lobes[i];
+    if (l.fac_mode != 0u) {
+      const float fac = fresnel_mix_factor(l.fac_ior, n, view);
+      const float term = l.fac_mode == 1u ? fac : 1.0f - fac;
+      l.wx = (l.px * term) * l.wx; l.wy = (l.py * term) * l.wy; l.wz = (l.pz * term) * l.wz;
+      if (l.wx == 0.0f && l.wy == 0.0f && l.wz == 0.0f) continue;
+      l.fac_mode = 0u;
+    }
+    out.lobes[out.num_lobes++] = l;
+  }
 }
 
 // ---- GGX ---------------------------------------------------------------------------------------

@@ -136,6 +136,9 @@ int bake_material(const phx_material& m, float sheen_L5, DevMaterial& out) {
     const phx_lobe& s = m.lobes[i];
     DevLobe& l = out.lobes[k];
     l.type = s.type; l.wx = s.weight[0]; l.wy = s.weight[1]; l.wz = s.weight[2];
+    l.fac_mode = s.fac_mode; l.fac_ior = s.fac_ior; l.px = s.pre_weight[0]; l.py = s.pre_weight[1]; l.pz = s.pre_weight[2];
+    if (s.fac_mode > PHX_FAC_MIX_A) return 1;
+    if (s.fac_mode != PHX_FAC_NONE) out.per_hit = 1;
     switch (s.type) {
       case PHX_LOBE_DIFFUSE: l.flags = B_REFLECT | B_DIFFUSE; break;
       case PHX_LOBE_OREN_NAYAR: {  // oren_nayar_t::precompute, params.hpp:36-43

@@ -102,7 +102,9 @@ struct LdsStack {
 // One stream serves BOTH queues: lanes are refilled from the workgroup's shadow-ray range first, then from
 // its closest-hit range; the any-hit / closest-hit distinction is a per-lane flag, so a launch has a single
 // drain phase (the tail where rays run out and lanes idle) instead of one per queue.
+#ifndef PHX_STEPS_PER_REFILL
 #define PHX_STEPS_PER_REFILL 1
+#endif
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
 struct DynQueue {            // DYN: the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform

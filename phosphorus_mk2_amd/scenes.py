@@ -23,6 +23,9 @@ class LobeDesc:
     yalpha: float = 0.0
     refract: int = 0
     r: float = 0.0
+    fac_mode: int = 0          # abi.FAC_*: per-hit Fresnel mix factor on this closure's weight (glass)
+    fac_ior: float = 0.0
+    pre_weight: Tuple[float, float, float] = (1.0, 1.0, 1.0)
 
 
 @dataclass
@@ -93,6 +96,8 @@ class SceneDesc:
                 d.type = l.type
                 d.weight[:] = [np.float32(x) for x in l.weight]
                 d.alpha, d.eta, d.xalpha, d.yalpha, d.refract, d.r = l.alpha, l.eta, l.xalpha, l.yalpha, l.refract, l.r
+                d.fac_mode, d.fac_ior = l.fac_mode, l.fac_ior
+                d.pre_weight[:] = [np.float32(x) for x in l.pre_weight]
         meshes = (abi.Mesh * len(self.meshes))()
         for i, m in enumerate(self.meshes):
             sets = (abi.FaceSet * len(m.sets))()

@@ -186,6 +186,9 @@ class HipDevice:
 
     @staticmethod
     def discover(options):
+        """xpu_t::discover (src/xpu.cpp:7-9): one device object per usable gfx950 GPU — all of them are meant to drain the frame's
+        one tile queue into its one film (src/core.cpp:103-115, see render_on).  An explicit `options.device_ordinal >= 0` restricts
+        the list to that GPU (what one rank of a one-process-per-GPU job wants)."""
         lib = load_library()
         o = options.pack()
         n = C.c_int(0)
@@ -193,7 +196,13 @@ class HipDevice:
         if options.host_only:
             return []
         _check(lib, rc, "phx_discover")
-        return [HipDevice.make(options)]
+        if options.device_ordinal >= 0 or n.value == 1:
+            return [HipDevice.make(options)]
+        devs = []
+        for i in range(n.value):
+            oi = Options(**{**options.__dict__, "device_ordinal": i})
+            devs.append(HipDevice.make(oi))
+        return devs
 
     @staticmethod
     def make(options):
@@ -300,6 +309,20 @@ class HipDevice:
             self.close()
         except Exception:
             pass
+
+
+def render_on(devices, scene_desc, seed=1, normals=False, tile_size=32, native_sink=True):
+    """The reference's frame on SEVERAL devices in one process (src/core.cpp:103-115): every device is started on the SAME tile
+    queue and the SAME film and joined in turn; no collective.  `devices` must have been preprocessed with `scene_desc`.
+    Returns (film array, [stats per device])."""
+    W, H = scene_desc.camera.width, scene_desc.camera.height
+    tiles = Tiles.make(W, H, tile_size)
+    film = Film(W, H, 4, normals)
+    for d in devices:
+        d.start(scene_desc, FrameState(seed, tiles, film, native_sink=native_sink))
+    for d in devices:
+        d.join()
+    return film.data, [d.stats() for d in devices]
 
 
 def render(scene_desc, spp=16, pps=1, depth=9, seed=1, normals=False, tile_size=32, rank=0, world=1, callback_tiles=False,

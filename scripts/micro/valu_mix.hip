@@ -1,0 +1,85 @@
+// Micro-benchmark behind the k_trace roofline: how fast can the chip run k_trace's own arithmetic —
+// the 8-box node test (bvh8.h: node_hitmask, octant permutation from an LDS table like the kernel) and the reference's
+// Moeller-Trumbore test (bvh8.h: mt_intersect) — when nothing else is in the way: operands in registers, all 64 lanes
+// active, no global memory, 8 waves per SIMD.  The two rates are the VALU ceiling k_trace is priced against: a frame that
+// needs V node visits and T triangle tests cannot finish faster than V / node_rate + T / tri_rate, however the rays are
+// fed.  (k_trace is VALU-issue bound: profiles/README.md.)
+// Build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I phosphorus_mk2_amd/csrc -o valu_mix scripts/micro/valu_mix.hip
+// Run:   ./valu_mix   -> one JSON line
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "bvh8.h"
+
+using namespace phx;
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+// MODE 0: node tests, MODE 1: triangle tests, MODE 2: the loop skeleton alone (what the perturbation of the operands costs)
+template <int MODE>
+__global__ void __launch_bounds__(256, 8) k(SceneGrid grid, int iters, uint32_t* out) {
+  __shared__ uint8_t lut[2048];
+  for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
+  __syncthreads();
+  const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t s = mix(tid + 1u), acc = 0;
+  // a plausible ray and node / triangle per lane; two words change every iteration so that nothing is hoisted
+  const float fx = (float)(s & 1023u) * (1.0f / 1024.0f) - 0.5f, fy = (float)((s >> 10) & 1023u) * (1.0f / 1024.0f) - 0.5f;
+  const RayCtx r = make_ray_ctx(v3(0.1f * fx, 0.1f * fy, 0.0f), v3(fx, fy, -0.8f));
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = mix(s + 17u * i);
+  w[2] = (w[2] & 0xff000000u) | 0x007a7a7au;  // scale exponents 2^-5
+  TriRec T;
+  T.v0x = fx; T.v0y = fy; T.v0z = -2.0f; T.e0x = 0.3f; T.e0y = 0.01f; T.e0z = 0.02f; T.e1x = 0.02f; T.e1y = 0.3f; T.e1z = 0.01f; T.prim = tid;
+  float tbest = 3.0e38f;
+  for (int it = 0; it < iters; ++it) {
+    s = s * 1664525u + 1013904223u;
+    if (MODE == 0) {
+      w[4 + (it & 7)] ^= s; w[0] += s >> 20;
+      const uint32_t hm = node_hitmask(w, grid, r, tbest, [&](uint32_t m) { return (uint32_t)lut[(r.oct_inv << 8) | m]; });
+      acc += hm;
+    } else if (MODE == 1) {
+      T.v0x += 1.0e-6f * (float)(s >> 24); T.e0y = -T.e0y;
+      float us, vs, ds;
+      if (mt_intersect(T, r.o, r.d, tbest, acc, us, vs, ds)) { acc += __float_as_uint(us) ^ __float_as_uint(vs); tbest = ds * 1.0000001f + 1.0f; }
+    } else {
+      w[4 + (it & 7)] ^= s; w[0] += s >> 20; acc += w[4] ^ w[0];
+    }
+  }
+  out[tid] = acc + __float_as_uint(tbest);
+}
+
+template <int MODE>
+static double run(int grid_blocks, int iters, uint32_t* d_out) {
+  SceneGrid g; for (int a = 0; a < 3; ++a) { g.lo[a] = -1.0f; g.cell[a] = 7.6e-6f; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid_blocks), dim3(256), 0, 0, g, iters / 8, d_out);  // warm-up
+  hipDeviceSynchronize();
+  double best = 1e30;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid_blocks), dim3(256), 0, 0, g, iters, d_out);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  return best * 1e-3;
+}
+
+int main() {
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount, blocks = cus * 8, iters = 20000;  // 8 blocks x 4 waves = 32 waves per CU = 8 per SIMD
+  uint32_t* d_out; hipMalloc((void**)&d_out, (size_t)blocks * 256 * 4);
+  const double t_skel = run<2>(blocks, iters, d_out), t_node = run<0>(blocks, iters, d_out), t_tri = run<1>(blocks, iters, d_out);
+  const double lanes = (double)blocks * 256.0;
+  // the skeleton (operand perturbation + loop) is subtracted: it is not part of the test being priced
+  const double node_rate = lanes * iters / (t_node - t_skel), tri_rate = lanes * iters / (t_tri - t_skel);
+  std::printf("{\"device\": \"%s\", \"cus\": %d, \"waves_per_simd\": 8, \"iters\": %d, \"t_skeleton_s\": %.6f, \"t_node_s\": %.6f, \"t_tri_s\": %.6f, "
+              "\"node_tests_per_s\": %.6e, \"tri_tests_per_s\": %.6e, \"ns_per_node_test_per_cu\": %.4f, \"ns_per_tri_test_per_cu\": %.4f}\n",
+              p.gcnArchName, cus, iters, t_skel, t_node, t_tri, node_rate, tri_rate, 1e9 * cus / node_rate, 1e9 * cus / tri_rate);
+  hipFree(d_out);
+  return 0;
+}

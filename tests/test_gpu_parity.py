@@ -297,8 +297,8 @@ def _room_scene():
     return scenes.SceneDesc([mesh], mats, scenes.CameraDesc(128, 96, fov=1.2))
 
 
-@pytest.mark.parametrize("builder", ["host", "device"])
-def test_plain_c_host_renders_the_same_film(xpu, orc, builder, tmp_path):
+@pytest.mark.parametrize("builder,ndev", [("host", 1), ("device", 1), ("host", 3)])
+def test_plain_c_host_renders_the_same_film(xpu, orc, builder, ndev, tmp_path):
     """examples/render_room.c drives the C ABI from C (no Python, no torch in that process); its film must equal the
     film of the same scene rendered through the ctypes mirror, and the oracle's."""
     import os
@@ -308,8 +308,12 @@ def test_plain_c_host_renders_the_same_film(xpu, orc, builder, tmp_path):
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True)
     out = str(tmp_path / "room.f32")
-    r = subprocess.run([exe, out] + (["device-bvh"] if builder == "device" else []), capture_output=True, text=True, timeout=120)
+    # ndev > 1: the C host makes that many devices (ordinal i % GPUs of the box), starts them all on ONE queue and ONE film
+    r = subprocess.run([exe, out, f"{builder}-bvh"] + ([str(ndev)] if ndev > 1 else []), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    if ndev > 1:
+        per_dev = [int(l.split("tiles")[1]) for l in r.stdout.splitlines() if l.startswith("device ")]
+        assert len(per_dev) == ndev and sum(per_dev) == 12  # 128x96 film: 4 x 3 tiles, every tile rendered exactly once
     c_film = np.fromfile(out, np.float32).reshape(96, 128, 4)
     sc = _room_scene()
     film, st = xpu.render(sc, spp=8, pps=1, depth=5, seed=7, native_sink=True, bvh_builder=builder)
@@ -381,17 +385,20 @@ def test_two_devices_drain_one_tile_queue(xpu, orc):
     for dv in devs:
         dv.preprocess(sc)
     for sink in ("callback", "native"):
-        tiles = xpu.Tiles.make(320, 208, 32)
-        film = xpu.Film(320, 208, 4)
-        for dv in devs:
-            dv.start(sc, xpu.FrameState(4, tiles, film, native_sink=(sink == "native")))
-        for dv in devs:
-            dv.join()
-        sts = [dv.stats() for dv in devs]
-        assert sum(s["tiles"] for s in sts) == len(tiles) == 70
+        film, sts = xpu.render_on(devs, sc, seed=4, native_sink=(sink == "native"))
+        assert sum(s["tiles"] for s in sts) == 70
         for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked"):
             assert sum(s[k] for s in sts) == st1[k]
-        assert bits_equal(film.data, one)
+        assert bits_equal(film, one)
+    # discover(): one device object per GPU of the box, each on its own ordinal
+    found = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=9, paths_per_sample=1))
+    assert len(found) >= 1 and all(isinstance(d, xpu.HipDevice) for d in found)
+    for d in found:
+        d.preprocess(sc)
+    film, sts = xpu.render_on(found, sc, seed=4)
+    assert bits_equal(film, one) and sum(s["tiles"] for s in sts) == 70
+    for d in found:
+        d.close()
     for dv in devs:
         dv.close()
     ref, _ = orc.Oracle(sc, spp=9).render(rng=orc.RNG_COUNTER, seed=4, threads=8)
