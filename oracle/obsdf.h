@@ -111,14 +111,44 @@ struct bsdf_t {
   float sheen_L5 = 0.0f;  // see sheen_lambda
   bool has_sheen_L5 = false;
 
-  // add_lobe (bsdf.hpp:54-82) for every closure of a recipe (material.cpp:218-305)
-  void from_material(const phx_material& mat, const V3& n) {
+  // What OSL computes at a hit for the one hit-dependent input of the reference's node shaders — the mix factor of Blender's
+  // glass node (plugins/blender/blender/shader.hpp:306-335): fresnel_dielectric_node.osl:16-20 on the shader globals of
+  // material_t::evaluate (material.cpp:425-436: I = hits.wi, N = n, backfacing = N.I < 0) with the OSL helper
+  // src/shaders/fresnel.h:1-19 (fp32, like every OSL float).  OSL itself is third-party and absent: "parity unpinned".
+  static float osl_fresnel_dielectric(float cosi, float eta) {
+    const float c = std::fabs(cosi);
+    float g = eta * eta - 1.0f + c * c;
+    if (g > 0.0f) {
+      g = std::sqrt(g);
+      const float A = (g - c) / (g + c);
+      const float B = (c * (g + c) - 1.0f) / (c * (g - c) + 1.0f);
+      return 0.5f * A * A * (1.0f + B * B);
+    }
+    return 1.0f;
+  }
+  static float fresnel_mix_factor(float ior, const V3& n, const V3& view) {
+    const float f = std::max(1.0e-5f, ior);
+    const bool backfacing = n.dot(view) < 0.0f;
+    const float eta = backfacing ? 1.0f / f : f;
+    return osl_fresnel_dielectric(view.dot(n), eta);
+  }
+
+  // add_lobe (bsdf.hpp:54-82) for every closure that material_t::eval_closure (material.cpp:218-305) meets at this hit:
+  // `view` = hits.wi.  A closure under a Fresnel-driven mix gets the weight (pre * term) * weight, the order eval_closure
+  // multiplies down the tree, and is absent when that is all zero (OSL: closure * 0 is the null closure).
+  void from_material(const phx_material& mat, const V3& n, const V3& view) {
     lobes = 0;
     for (uint32_t i = 0; i < mat.num_lobes && i < PHX_MAX_LOBES; ++i) {
       const phx_lobe& s = mat.lobes[i];
       lobe_t& l = lobe[lobes];
       l = lobe_t();
       l.type = s.type; l.weight = V3(s.weight[0], s.weight[1], s.weight[2]); l.n = n;
+      if (s.fac_mode != PHX_FAC_NONE) {
+        const float fac = fresnel_mix_factor(s.fac_ior, n, view);
+        const float term = s.fac_mode == PHX_FAC_MIX_B ? fac : 1.0f - fac;
+        l.weight = V3((s.pre_weight[0] * term) * s.weight[0], (s.pre_weight[1] * term) * s.weight[1], (s.pre_weight[2] * term) * s.weight[2]);
+        if (l.weight.x == 0.0f && l.weight.y == 0.0f && l.weight.z == 0.0f) continue;
+      }
       switch (s.type) {
         case PHX_LOBE_DIFFUSE: l.flags = PHX_BSDF_REFLECT | PHX_BSDF_DIFFUSE; break;
         case PHX_LOBE_OREN_NAYAR: {

@@ -245,7 +245,7 @@ struct tile_renderer_t {
         const phx_material& m = sc.materials[material];
         out.e[i] = V3(m.emission[0], m.emission[1], m.emission[2]);
         out.material[i] = material;
-        out.bsdf[i].from_material(m, out.n[i]);
+        out.bsdf[i].from_material(m, out.n[i], out.wi[i]);
         out.bsdf[i].sheen_L5 = O.sheen_L5;
       }
     }
@@ -630,7 +630,7 @@ int orc_bsdf_f(void* h, uint32_t material, uint32_t n_items, const float* n3, co
   oracle_t* o = (oracle_t*)h;
   if (material >= o->scene.materials.size()) return 1;
   for (uint32_t i = 0; i < n_items; ++i) {
-    bsdf_t b; b.from_material(o->scene.materials[material], V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2])); b.sheen_L5 = o->sheen_L5;
+    bsdf_t b; b.from_material(o->scene.materials[material], V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2])); b.sheen_L5 = o->sheen_L5;
     V3 f = b.f(V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]));
     f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
   }
@@ -641,7 +641,7 @@ int orc_bsdf_sample(void* h, uint32_t material, uint32_t n_items, const float* n
   oracle_t* o = (oracle_t*)h;
   if (material >= o->scene.materials.size()) return 1;
   for (uint32_t i = 0; i < n_items; ++i) {
-    bsdf_t b; b.from_material(o->scene.materials[material], V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2])); b.sheen_L5 = o->sheen_L5;
+    bsdf_t b; b.from_material(o->scene.materials[material], V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2])); b.sheen_L5 = o->sheen_L5;
     V3 wo(0.0f); float p = 0; uint32_t fl = 0;
     V3 f = b.sample(V2(u2[2 * i], u2[2 * i + 1]), V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo, p, fl);
     if (p == 0.0f) { wo = V3(0.0f); f = V3(0.0f); fl = 0; }  // terminated: outputs defined as zero

@@ -361,7 +361,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     sc.num_cus = (uint32_t)prop.multiProcessorCount;
   }
   sc.diffuse_only = 1;
-  for (auto& m : mats) for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0;
+  for (auto& m : mats) { if (m.per_hit) sc.diffuse_only = 0; for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0; }
   d->num_materials = s->num_materials;
   d->bvh_nodes = bvh_node_count;
   d->bvh_bytes = bvh_elems * sizeof(PoolElem);

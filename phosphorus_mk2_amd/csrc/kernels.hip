@@ -455,10 +455,15 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
     if (tri != 0xffffffffu) {
       const TriRec T = sc.tris[tri];
       const uint32_t pm = T.material;
-      const DevMaterial& m = sc.materials[pm & 0x7fffffffu];
       const v3 p = o + d * h.x;            // hits.p = p + wi*d
       const v3 wo = -d;                    // hits.wi = -wi
       const v3 n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+      // material_t::evaluate (material.cpp:419-458): the closure list at this hit.  A constant recipe is read from the table; a
+      // material with a hit-dependent weight (glass: Fresnel-driven mix) gets its weights resolved for (n, hits.wi) first.
+      const DevMaterial* mp = &sc.materials[pm & 0x7fffffffu];
+      DevMaterial mh;
+      if (!DIFFUSE_ONLY && mp->per_hit) { material_at_hit(*mp, n, wo, mh); mp = &mh; }
+      const DevMaterial& m = *mp;
       if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
       const v3 e(m.ex, m.ey, m.ez);
       if (depth == 0 || specular) { add_e = e; add_rad = true; }  // spt.hpp:177-179
@@ -618,8 +623,10 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_scatter_film(PassBuffers pb, floa
 __global__ void k_bsdf_f(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const v3 f = bsdf_f(*mat, v3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]),
-                      v3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]));
+  const v3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), view(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);  // f(wi = to the light, wo = hits.wi)
+  DevMaterial mh; const DevMaterial* mp = mat;
+  if (mat->per_hit) { material_at_hit(*mat, nn, view, mh); mp = &mh; }
+  const v3 f = bsdf_f(*mp, nn, v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), view);
   f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
 }
 __global__ void k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* u2,
@@ -627,8 +634,10 @@ __global__ void k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   v3 wo; float p; uint32_t fl;
-  v3 f = bsdf_sample(*mat, v3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), u2[2 * i], u2[2 * i + 1],
-                     v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo, p, fl);
+  const v3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), view(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);  // sample(u, wi = hits.wi)
+  DevMaterial mh; const DevMaterial* mp = mat;
+  if (mat->per_hit) { material_at_hit(*mat, nn, view, mh); mp = &mh; }
+  v3 f = bsdf_sample(*mp, nn, u2[2 * i], u2[2 * i + 1], view, wo, p, fl);
   if (p == 0.0f) { wo = v3(0.0f); f = v3(0.0f); fl = 0; }
   wo3[3 * i] = wo.x; wo3[3 * i + 1] = wo.y; wo3[3 * i + 2] = wo.z;
   f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z; pdf[i] = p; flags[i] = fl;

@@ -318,6 +318,25 @@ def closure_zoo():
     ]
 
 
+def glass(ior=1.45, roughness=0.0, Cs_refraction=(1.0, 1.0, 1.0), Cs_reflection=(1.0, 1.0, 1.0)):
+    """Blender's glass node as the reference's exporter builds it (plugins/blender/blender/shader.hpp:306-335):
+    mix_closure_node(A = refraction_bsdf_node(IoR, roughness), B = glossy_bsdf_node(roughness), fac = fresnel_dielectric_node(IoR)),
+    i.e. what closures.bake_material returns for that node group: two closures whose weights depend on the hit."""
+    from . import closures as cl
+    tree = cl.mix_closure_node(A=cl.refraction_bsdf_node(Cs=Cs_refraction, IoR=ior, roughness=roughness),
+                               B=cl.glossy_bsdf_node(Cs=Cs_reflection, roughness=roughness), fac=cl.fresnel_dielectric_node(IoR=ior))
+    return cl.flatten(tree)
+
+
+def glass_blobs(width=96, height=64):
+    """smooth_blobs() with one blob of sharp glass (IoR 1.45) and one of frosted glass (IoR 1.33, roughness 0.2)"""
+    s = smooth_blobs(width, height)
+    s.materials[1] = glass(1.45, 0.0, (0.95, 0.98, 0.95), (1.0, 1.0, 1.0))
+    s.materials[2] = glass(1.33, 0.2, (0.9, 0.9, 1.0), (0.9, 0.9, 0.9))
+    s.name = "glass_blobs"
+    return s
+
+
 def multi_material_soup(n, seed=1234, width=1280, height=720):
     """Declared stand-in for the BMW configs (no scene data ships with the reference):
     Soup(N) whose triangles cycle through closure_zoo() + 4 more diffuse tints = 16 closure recipes."""

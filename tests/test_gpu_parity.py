@@ -167,6 +167,36 @@ def test_render_all_closures_matches_oracle(xpu, orc):
     assert bits_equal(film[..., :3][fin], ref[..., :3][fin])
 
 
+def test_glass_per_hit_closures_match_oracle(xpu, orc):
+    """Blender's glass node (mix(refraction, glossy, fresnel_dielectric(I.N, backfacing ? 1/IoR : IoR)),
+    plugins/blender/blender/shader.hpp:306-335): closure weights evaluated at every hit (bsdf.h: material_at_hit), closures
+    with an all-zero weight dropped (total internal reflection leaves ONE lobe).  Known answers and a film, bit for bit."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.glass_blobs(160, 96)
+    dev = _device(xpu, sc)
+    O = orc.Oracle(sc, spp=1)
+    rng = np.random.default_rng(9)
+    k = 4096
+    def unit(m):
+        v = rng.normal(size=(m, 3)); return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    n, wi, wo = unit(k), unit(k), unit(k)
+    n[:2] = [[0, 1, 0], [0, 1, 0]]; wi[:2] = [[0.9, -0.43588990, 0.0], [0.0, 1.0, 0.0]]  # total internal reflection from inside; normal incidence
+    u2 = rng.random((k, 2)).astype(np.float32)
+    for m in (1, 2):  # sharp glass, frosted glass
+        assert bits_equal(dev.bsdf_f(m, n, wi, wo), O.bsdf_f(m, n, wi, wo)), f"glass f, material {m}"
+        wg, fg, pg, flg = dev.bsdf_sample(m, n, wi, u2); w0, f0, p0, fl0 = O.bsdf_sample(m, n, wi, u2)
+        assert np.array_equal(flg, fl0) and bits_equal(pg, p0) and bits_equal(wg, w0) and bits_equal(fg, f0), f"glass sample, material {m}"
+    dev.close()
+    film, st, (ref, ost) = _render_both(xpu, orc, sc, spp=16, seed=5)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"]
+    fin = np.isfinite(ref[..., :3]).all(axis=-1)
+    assert fin.mean() > 0.99 and np.array_equal(fin, np.isfinite(film[..., :3]).all(axis=-1))
+    assert max_pixel_l2(film[fin], ref[fin]) < L2_TOL and bits_equal(film[..., :3][fin], ref[..., :3][fin])
+    # the glass changes the picture: the same scene with Lambert blobs is a different film
+    plain, _ = xpu.render(scenes.smooth_blobs(160, 96), spp=16, seed=5)
+    assert not bits_equal(plain, film)
+
+
 def test_general_closures_at_film_size(xpu, orc):
     """the general k_shade (all seven lobe models, 16 closure recipes: the declared stand-in of the BMW configs) on a 640x360
     film with an edge band (360 = 11 * 32 + 8), whole frame against the oracle"""
