@@ -208,11 +208,16 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #if PHX_COUNT
         if (ni < ntop) ++cnt_lds[any ? 1 : 0]; else ++cnt_mem[any ? 1 : 0];
 #endif
-        if (ni < ntop) {  // top-of-tree nodelet staged in LDS: four ds_read_b128 instead of four L1 requests per lane
-          const uint4* s4 = top + ni * (PHX_NODE_LDS_BYTES / 16u);
+        // top-of-tree nodelets are staged in LDS: four ds_read_b128 instead of four L1 requests per lane.  The LDS lanes go
+        // first: both groups write the same registers, so the second group waits for the first one's data — a few dozen cycles
+        // for LDS, several hundred for the L1/L2 path if it went first.
+        const bool in_lds = ni < ntop;
+        {
+          const uint4* s4 = top + (in_lds ? ni : 0u) * (PHX_NODE_LDS_BYTES / 16u);  // every lane reads (element 0 when its node is not staged)
 #pragma unroll
           for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-        } else {
+        }
+        if (!in_lds) {
           const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ni * 4u;
 #pragma unroll
           for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
