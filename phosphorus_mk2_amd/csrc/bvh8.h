@@ -179,6 +179,9 @@ typedef float phx_f2 __attribute__((ext_vector_type(2)));
 #else
 #define PHX_USE_PK 0
 #endif
+#ifndef PHX_SIGN_ACCUM
+#define PHX_SIGN_ACCUM 1
+#endif
 #ifndef PHX_F16_PLANES
 #define PHX_F16_PLANES 0  /* experiment, measured 4 % SLOWER (below) */
 #endif
@@ -223,6 +226,34 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
       }
     }
   }
+#elif defined(__HIP_DEVICE_COMPILE__) && PHX_SIGN_ACCUM
+  // Same test, cheaper instructions (scripts/micro/valu_ops.hip: v_mul/v_add/v_sub issue in 2 clocks, v_max/v_min/v_cmp/
+  // v_cndmask/v_cvt in 4): the clamps against 0 and tmax become two subtractions, "miss" is the sign bit of
+  // (tf - tn) | (tmax - tn) | tf, and a funnel shift collects it — no compare, no select.  Children run 7..0 so that child j
+  // ends at bit j.  tf + 0 turns an exit distance of -0 into +0 (t = -0 is a valid Moeller-Trumbore distance).
+  uint32_t miss = 0;
+  const float tmaxp = tmax * pad_far;
+#pragma unroll
+  for (int half = 1; half >= 0; --half) {
+    const uint32_t nearx = nx ? w[10 + half] : w[4 + half], farx = nx ? w[4 + half] : w[10 + half];
+    const uint32_t neary = ny ? w[12 + half] : w[6 + half], fary = ny ? w[6 + half] : w[12 + half];
+    const uint32_t nearz = nz ? w[14 + half] : w[8 + half], farz = nz ? w[8 + half] : w[14 + half];
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const int sh = 8 * j;
+      const float tnx = fmaf((float)((nearx >> sh) & 0xffu), ax, bx);
+      const float tny = fmaf((float)((neary >> sh) & 0xffu), ay, by);
+      const float tnz = fmaf((float)((nearz >> sh) & 0xffu), az, bz);
+      const float tfx = fmaf((float)((farx >> sh) & 0xffu), ax, bx);
+      const float tfy = fmaf((float)((fary >> sh) & 0xffu), ay, by);
+      const float tfz = fmaf((float)((farz >> sh) & 0xffu), az, bz);
+      const float tn = fmaxf(fmaxf(tnx, tny), tnz);
+      const float tf = fminf(fminf(tfx, tfy), tfz) * pad_far;
+      const uint32_t m = __float_as_uint(tf - tn) | __float_as_uint(tmaxp - tn) | __float_as_uint(tf + 0.0f);
+      miss = __builtin_amdgcn_alignbit(miss, m, 31);  // (miss << 1) | (m >> 31)
+    }
+  }
+  hit8 = ~miss & 0xffu;
 #else
 #if PHX_USE_PK
   const phx_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
