@@ -2,7 +2,7 @@
 """Traversal work per ray from the instrumented build (libphx_hip_count.so: `make -C phosphorus_mk2_amd/csrc variant NAME=count
 EXTRA=-DPHX_COUNT=1`): node visits served from LDS / through the vector L1, triangle tests, and how full the wave's node and
 triangle blocks run.  python scripts/count_work.py [--triangles N --width W --height H --spp S --builder host|device]"""
-import argparse, json, os, sys
+import argparse, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["PHX_LIB"] = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
@@ -14,7 +14,7 @@ a = p.parse_args()
 sc = scenes.soup(a.triangles, width=a.width, height=a.height)
 film, st = xpu.render(sc, spp=a.spp, pps=1, depth=9, seed=1, native_sink=True, bvh_builder=a.builder)
 assert st["instrumented"] == 1
-out = {"triangles": a.triangles, "film": [a.width, a.height], "spp": a.spp, "builder": a.builder, "bvh_bytes": st["bvh_bytes"], "bvh_nodes": st["bvh_nodes"],
+out = {"film_sha1": hashlib.sha1(film.tobytes()).hexdigest(), "triangles": a.triangles, "film": [a.width, a.height], "spp": a.spp, "builder": a.builder, "bvh_bytes": st["bvh_bytes"], "bvh_nodes": st["bvh_nodes"],
        "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]}}
 for k, name in ((0, "closest"), (1, "shadow")):
     rays = st["rays_closest"] if k == 0 else st["rays_shadow"]

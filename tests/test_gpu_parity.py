@@ -435,6 +435,33 @@ def test_two_devices_drain_one_tile_queue(xpu, orc):
     assert bits_equal(one[..., :3], ref[..., :3])
 
 
+def test_instrumented_build_counts_the_same_frame(xpu, tmp_path):
+    """libphx_hip_count.so (the same sources with -DPHX_COUNT=1: bench.py's roofline reads node visits and triangle tests from it)
+    must render the very same film, and its counters must add up: every ray visits the root, every wave iteration runs a block."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
+    if not os.path.exists(lib):
+        pytest.skip("instrumented variant not built (make -C phosphorus_mk2_amd/csrc variant NAME=count EXTRA=-DPHX_COUNT=1)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "count_work.py"), "--triangles", "20000", "--width", "320", "--height", "192", "--spp", "16"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    w = json.loads(r.stdout.strip().splitlines()[-1])
+    from phosphorus_mk2_amd import scenes
+    import hashlib
+    film, st = xpu.render(scenes.soup(20000, width=320, height=192), spp=16, seed=1)
+    assert hashlib.sha1(film.tobytes()).hexdigest() == w["film_sha1"]  # same film, bit for bit
+    assert st["instrumented"] == 0 and st["node_visits_mem"] == [0, 0]  # the product library counts nothing
+    assert w["closest"]["rays"] == st["rays_closest"] and w["shadow"]["rays"] == st["rays_shadow"]
+    for k in ("closest", "shadow"):
+        assert w[k]["node_visits_lds_per_ray"] >= 1.0  # the root is staged in LDS
+        assert 1.0 <= w[k]["node_visits_lds_per_ray"] + w[k]["node_visits_mem_per_ray"] < 100 and 0 < w[k]["tri_tests_per_ray"] < 100
+    assert w["wave"]["node_block_execs"] <= w["wave"]["iterations"] and 1 <= w["wave"]["lanes_per_node_block"] <= 64
+
+
 def test_error_behaviour(xpu):
     from phosphorus_mk2_amd import scenes
     dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1))
