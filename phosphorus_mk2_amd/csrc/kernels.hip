@@ -32,9 +32,18 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 // __ballot/__popcll give the rank inside the wave, the waves' counts are summed through LDS, and ONE
 // global atomic per workgroup reserves the slots (a returning atomic on one address sustains only
 // ~90 ops/us chip-wide — per-wave atomics made k_shade atomic-bound).  All threads of the block must call.
-#define PHX_SHADE_BLOCK 512
+#ifndef PHX_SHADE_BLOCK_D
+#define PHX_SHADE_BLOCK_D 512  /* k_shade<DIFFUSE_ONLY>: threads per workgroup */
+#endif
+#ifndef PHX_SHADE_BLOCK_G
+#define PHX_SHADE_BLOCK_G 512  /* general k_shade (measured on the 16-recipe stand-in: 256: +4 % shade time, 128: +29 %, 64: +144 % — one atomic per workgroup and append) */
+#endif
+#ifndef PHX_SHADE_WAVES_G
+#define PHX_SHADE_WAVES_G 4    /* general k_shade: waves per SIMD the register allocator must leave room for */
+#endif
+template <int SHADE_BLOCK>
 __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, uint32_t* lds /* [2 * waves + 2] */, int which) {
-  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = PHX_SHADE_BLOCK >> 6;
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = SHADE_BLOCK >> 6;
   const unsigned long long mask = __ballot(want);
   uint32_t* cnt = lds + which * (nwaves + 1);
   if (lane == 0) cnt[wave] = (uint32_t)__popcll(mask);
@@ -399,7 +408,8 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
 }
 
 template <bool DIFFUSE_ONLY, bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
-__global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+__global__ void __launch_bounds__(DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(DIFFUSE_ONLY ? 4 : PHX_SHADE_WAVES_G, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+  constexpr int PHX_SHADE_BLOCK = DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q];
   uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
@@ -557,12 +567,12 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK) __attribute__((amdgpu_waves_p
     }
   }
   // ---- stream compaction: survivors -> next ray queue, unmasked NEE rays -> shadow queue
-  const uint32_t no = block_append(alive, &pb.counters[q ^ 1], lds_cnt, 0);
+  const uint32_t no = block_append<PHX_SHADE_BLOCK>(alive, &pb.counters[q ^ 1], lds_cnt, 0);
   if (alive) {
     pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
     pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
   }
-  const uint32_t ns = block_append(want_shadow, &pb.counters[CNT_SHADOW + sq], lds_cnt, 1);
+  const uint32_t ns = block_append<PHX_SHADE_BLOCK>(want_shadow, &pb.counters[CNT_SHADOW + sq], lds_cnt, 1);
   if (want_shadow) {
     pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
     pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
@@ -755,7 +765,8 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   }
 }
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays) {
-  const dim3 g((capacity + PHX_SHADE_BLOCK - 1) / PHX_SHADE_BLOCK), b(PHX_SHADE_BLOCK);
+  const uint32_t sb = sc.diffuse_only ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
+  const dim3 g((capacity + sb - 1) / sb), b(sb);
   if (sc.diffuse_only) {
     if (camera_rays) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
     else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, stream, sc, pb, q, sq, sample0);

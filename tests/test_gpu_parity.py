@@ -435,6 +435,69 @@ def test_two_devices_drain_one_tile_queue(xpu, orc):
     assert bits_equal(one[..., :3], ref[..., :3])
 
 
+def _random_scene(seed):
+    """a scene nobody designed: 2-4 meshes (indexed vertices shared between faces, smooth and flat faces mixed, per-vertex or
+    per-corner normals), 3-6 materials drawn from the closure zoo and the glass node, 1-2 emissive face sets, an optional
+    environment, a camera that is not the identity, a film whose width and height are not multiples of the tile size"""
+    from phosphorus_mk2_amd import abi, scenes
+    rng = np.random.default_rng(seed)
+    zoo = scenes.closure_zoo()
+    mats = [zoo[int(k)] for k in rng.choice(len(zoo), int(rng.integers(2, 5)), replace=False)]
+    if rng.random() < 0.7:
+        mats.append(scenes.glass(float(rng.uniform(1.2, 1.8)), float(rng.choice([0.0, 0.15])), tuple(rng.uniform(0.8, 1.0, 3)), (1.0, 1.0, 1.0)))
+    n_surface = len(mats)
+    mats.append(scenes.emitter(*scenes.LE)); mats.append(scenes.emitter(3.0, 4.0, 5.0))
+    meshes = []
+    for mi in range(int(rng.integers(2, 5))):
+        g = int(rng.integers(3, 9))  # a g x g grid of vertices bent into a bumpy sheet: every inner vertex is shared by six faces
+        u, v = np.meshgrid(np.linspace(-1, 1, g), np.linspace(-1, 1, g))
+        c = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(-3.2, -1.8)])
+        ax = rng.normal(size=(3, 3)); ax, _ = np.linalg.qr(ax)
+        p = (u[..., None] * ax[0] + v[..., None] * ax[1]) * rng.uniform(0.3, 0.9) + ax[2] * 0.15 * np.sin(3 * u + mi)[..., None] * np.cos(2 * v)[..., None] + c
+        verts = p.reshape(-1, 3).astype(np.float32)
+        idx = np.arange(g * g).reshape(g, g)
+        f = np.concatenate([np.stack([idx[:-1, :-1], idx[1:, :-1], idx[:-1, 1:]], -1).reshape(-1, 3), np.stack([idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]], -1).reshape(-1, 3)]).astype(np.uint32)
+        nrm = np.zeros_like(verts)
+        fn = np.cross(verts[f[:, 1]] - verts[f[:, 0]], verts[f[:, 2]] - verts[f[:, 0]])
+        for k in range(3):
+            np.add.at(nrm, f[:, k], fn)
+        nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+        smooth = (rng.random(len(f)) < 0.6).astype(np.uint8)
+        order = rng.permutation(len(f)); cut = int(rng.integers(1, len(f)))
+        sets = [(int(rng.integers(0, n_surface)), order[:cut].astype(np.uint32)), (int(rng.integers(0, n_surface)), order[cut:].astype(np.uint32))]
+        if rng.random() < 0.5:
+            meshes.append(scenes.MeshDesc(verts, f, sets, normals=nrm, smooth=smooth))
+        else:  # one normal per face corner (mesh.cpp:188-192)
+            meshes.append(scenes.MeshDesc(verts, f, sets, normals=nrm[f.reshape(-1)], smooth=smooth, flags=abi.MESH_UV_PER_VERTEX))
+    meshes.append(scenes._quad((-1.5, 1.6, -1.5), (-1.5, 1.6, -3.5), (1.5, 1.6, -3.5), (1.5, 1.6, -1.5), n_surface))
+    if rng.random() < 0.5:
+        meshes.append(scenes._quad((-1.9, -0.5, -1.5), (-1.9, 0.5, -1.5), (-1.9, 0.5, -2.5), (-1.9, -0.5, -2.5), n_surface + 1))
+    sc = scenes.SceneDesc(meshes, mats, scenes.CameraDesc(int(rng.integers(5, 14)) * 8, int(rng.integers(30, 90)), fov=float(rng.uniform(0.9, 1.9))))
+    if rng.random() < 0.5:
+        sc.materials.append(scenes.MaterialDesc(lobes=[], emission=(0.2, 0.25, 0.3))); sc.environment_material = len(sc.materials) - 1
+    th = rng.uniform(-0.3, 0.3); M = np.eye(4, dtype=np.float32)
+    M[0, 0] = np.cos(th); M[0, 2] = -np.sin(th); M[2, 0] = np.sin(th); M[2, 2] = np.cos(th); M[3, :3] = rng.uniform(-0.2, 0.2, 3)  # row-vector convention
+    sc.camera.to_world = M
+    return sc
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_match_oracle(xpu, orc, seed):
+    """eight scenes nobody designed (shared vertices, mixed smooth / flat faces, zoo + glass materials, one or two lights, optional
+    environment, rotated and shifted camera, ragged film), both builders, odd spp and depth: counts and film bit for bit"""
+    sc = _random_scene(1000 + seed)
+    spp, depth = [1, 4, 9, 16][seed % 4], [9, 3, 6, 9][(seed // 2) % 4]
+    builder = "device" if seed % 2 else "host"
+    film, st = xpu.render(sc, spp=spp, pps=1, depth=depth, seed=seed, normals=True, bvh_builder=builder, samples_in_flight=[0, 3][seed % 2])
+    ref, ost, nrm = orc.Oracle(sc, spp=spp, pps=1, depth=depth).render(rng=orc.RNG_COUNTER, seed=seed, threads=8, normals=True)
+    for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    fin = np.isfinite(ref[..., :3]).all(axis=-1)
+    assert fin.mean() > 0.98 and np.array_equal(fin, np.isfinite(film[..., :3]).all(axis=-1))
+    assert max_pixel_l2(film[fin], ref[fin]) < L2_TOL and bits_equal(film[..., :3][fin], ref[..., :3][fin])
+    assert bits_equal(film[..., 4:7], nrm)
+
+
 def test_instrumented_build_counts_the_same_frame(xpu, tmp_path):
     """libphx_hip_count.so (the same sources with -DPHX_COUNT=1: bench.py's roofline reads node visits and triangle tests from it)
     must render the very same film, and its counters must add up: every ray visits the root, every wave iteration runs a block."""
