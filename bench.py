@@ -308,7 +308,7 @@ def secondary_record(xpu, scenes, name, triangles, width, height, spp, args, cpu
     ref_visits = None
     if cpu_seconds > 0:
         logical, _, share = host_cpus()
-        base, ref_visits = cpu_baseline(scene, like, seconds=cpu_seconds, thread_counts={1: 0.2, max(1, min(logical, int(round(share)))): 0.5, min(64, logical): 1.0})
+        base, ref_visits = cpu_baseline(scene, like, seconds=cpu_seconds, thread_counts={1: 0.2, max(1, min(logical, int(round(share)))): 1.0, min(64, logical): 0.5})
         rec["cpu_baseline"] = base
         rec["gpu_over_cpu"] = value / base["value"]
     rec["roofline"] = roofline(acc, 2, work, pmc, src, ref_visits, like)
