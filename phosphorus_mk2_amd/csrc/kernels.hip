@@ -665,7 +665,7 @@ void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_s
 }
 namespace {
 struct TraceEnv {
-  int gmul, gmul0, inter0, dyn, dyn_grid;
+  int gmul, gmul0, inter0, dyn, dyn_grid, wg_cap;
   uint32_t refill, block_env, ntop_env, min_chunks, target_chunks;
 };
 const TraceEnv& trace_env() {
@@ -677,6 +677,7 @@ const TraceEnv& trace_env() {
     // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
     t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
     t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
+    t.wg_cap = geti("PHX_TRACE_WG_CAP", 0);  // experiment: at most this many k_trace workgroups per CU (leaves wave slots to another stream)
     // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
     t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : 4);
     return t;
@@ -736,6 +737,7 @@ TracePlan trace_plan(const DevScene& sc) {
       if (wgs * (blk / 64u) > best_waves) { best_waves = wgs * (blk / 64u); P.block = blk; P.ntop = nt; P.lds_bytes = l; P.wg_per_cu = wgs; }
     }
   }
+  if (E.wg_cap > 0 && P.wg_per_cu > (uint32_t)E.wg_cap) P.wg_per_cu = (uint32_t)E.wg_cap;
   if (P.wg_per_cu == 0) P.wg_per_cu = 1;  // deeper than the LDS can hold even with 256 threads: the launch will report the error
   return P;
 }
