@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <future>
 #include <thread>
 
@@ -185,12 +186,14 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
   // distribute(n, j) = min over k of cost(left, k) + cost(right, j - k); cost(n, i) = min(distribute(n, i), cost(n, i - 1)).
   // Children are allocated after their parents (alloc()), so decreasing index order is bottom-up.  The greedy top-down collapse
   // it replaces left the 8-wide nodes 55 % full (4.4 children); a node visit costs ~2.4 triangle tests on the device.
-  // Measured on the device (Soup frames, k_trace ms per frame, greedy -> optimal): 100 k triangles 75.3 -> 77.8 (the optimal cut
-  // hangs small triangles below large nodes, whose 8-bit grids inflate their boxes: +13 % triangle tests on that frame),
-  // 300 k 89.2 -> 82.7, 1 M 98.3 -> 93.6, 3 M 109.2 -> 100.1, 10 M 250.9 -> 246.0: optimal from 200 k triangles up.
-  // PHX_COLLAPSE=0 / 1 forces the greedy / the optimal collapse.
+  // Measured on the device (Soup frames, k_trace ms per frame, greedy -> this optimum): 100 k triangles 75.3 -> 77.8 (it hangs
+  // small triangles below large nodes, whose 8-bit grids inflate their boxes: +13 % triangle tests on that frame), 300 k 89.2 ->
+  // 82.7, 1 M 98.3 -> 93.6, 3 M 109.2 -> 100.1, 10 M 250.9 -> 246.0.  Mode 2 below optimises on the boxes the traversal really
+  // tests and wins or ties everywhere (greedy / mode 1 / mode 2: 100 k 67.8 / 70.9 / 67.0 ms, 300 k 84.3 / 76.4 / 76.6, 1 M 95.6 /
+  // 89.7 / 87.5): it is the default.  PHX_COLLAPSE=0 / 1 / 2 forces greedy / optimal on true boxes / optimal on quantised boxes.
   static const int collapse_env = getenv("PHX_COLLAPSE") ? atoi(getenv("PHX_COLLAPSE")) : -1;
-  const bool use_dp = collapse_env < 0 ? n >= 200000u : collapse_env != 0;
+  const int collapse_mode = collapse_env < 0 ? 2 : collapse_env;
+  const bool use_dp = collapse_mode == 1;
   const float C_NODE = 2.4f, C_TRI = 1.0f;  // with one triangle per leaf slot only the sum of the nodes' areas is left to minimise
   std::vector<float> dp_cost; std::vector<uint8_t> dp_split;
   if (use_dp) {
@@ -214,6 +217,108 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     }
   }
 
+  // ---- mode 2: the same optimisation on the boxes the traversal really tests.  A child's box is stored on its parent's 8-bit
+  // grid, so it is inflated by up to two grid units per axis of THAT parent: a small triangle hung below a large node is tested
+  // far more often than its own area says (what made the classic optimum lose at 100 k triangles).  The cost of a cut element
+  // therefore depends on the 8-wide node m it hangs below: sub(m) = min over cuts K of m's binary subtree, |K| <= 8, of the sum
+  // over c in K of area(box(c) inflated by m's grid) * (C_NODE | C_TRI) + (sub(c) if c is inner).  A cut of <= 8 elements lies
+  // within 7 binary levels below m, so sub(m) is an exact local dynamic programme over (descendant, slots) given the sub() of the
+  // descendants: bottom-up over the binary tree (children have larger indices than their parents).
+  struct Cut { uint32_t node[8]; uint8_t count; };
+  std::vector<Cut> cuts;
+  if (collapse_mode == 2) {
+    const uint32_t nn = B.next.load();
+    std::vector<float> sub(nn, 0.0f);
+    cuts.resize(nn);
+    const float CN = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f, CT = 1.0f;  // measured VALU time per node visit : per triangle test
+    struct Local {
+      float best[256][9]; uint8_t split[256][9]; uint8_t done[256][9]; uint32_t node[256];
+    };
+    auto solve = [&](uint32_t m, Local& L) {
+      const Node2& M = B.nodes[m];
+      float g2[3];  // two grid units of m per axis
+      for (int a = 0; a < 3; ++a) {
+        const double ext = (double)M.box.hi[a] - (double)M.box.lo[a];
+        int e = -126;
+        if (ext > 0.0) { e = (int)std::ceil(std::log2(ext * 1.00001 / 255.0)); }
+        e = std::max(-126, std::min(127, e));
+        g2[a] = 2.0f * (float)std::ldexp(1.0, e);
+      }
+      auto areaq = [&](const Box& b) {
+        const float dx = b.hi[0] - b.lo[0] + g2[0], dy = b.hi[1] - b.lo[1] + g2[1], dz = b.hi[2] - b.lo[2] + g2[2];
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+      };
+      std::memset(L.done, 0, sizeof(L.done));
+      // best(h, j): cheapest way to hang the binary node at heap position h below m using <= j slots
+      std::function<float(uint32_t, uint32_t, int)> best = [&](uint32_t h, uint32_t v, int j) -> float {
+        if (L.done[h][j]) return L.best[h][j];
+        L.node[h] = v;
+        const Node2& nd = B.nodes[v];
+        float r; uint8_t sp = 0;
+        if (nd.count > 0) r = areaq(nd.box) * CT;
+        else {
+          r = areaq(nd.box) * CN + sub[v];  // as ONE slot: an 8-wide node of its own
+          if (j > 1 && h < 128) {
+            for (int k = 1; k < j; ++k) {
+              const float t = best(2 * h, nd.left, k) + best(2 * h + 1, nd.right, j - k);
+              if (t < r) { r = t; sp = (uint8_t)k; }
+            }
+          }
+        }
+        L.best[h][j] = r; L.split[h][j] = sp; L.done[h][j] = 1;
+        return r;
+      };
+      float r = FLT_MAX; int bk = 1;
+      for (int k = 1; k < 8; ++k) {
+        const float t = best(2, M.left, k) + best(3, M.right, 8 - k);
+        if (t < r) { r = t; bk = k; }
+      }
+      sub[m] = r;
+      // the cut that achieves it
+      Cut& C = cuts[m]; C.count = 0;
+      struct Item { uint32_t h; int j; };
+      Item st[16]; int top = 0;
+      st[top++] = Item{3, 8 - bk}; st[top++] = Item{2, bk};
+      while (top > 0) {
+        const Item it = st[--top];
+        const uint8_t k = L.split[it.h][it.j];
+        if (k == 0) { C.node[C.count++] = L.node[it.h]; continue; }
+        st[top++] = Item{2 * it.h + 1, it.j - (int)k}; st[top++] = Item{2 * it.h, (int)k};
+      }
+    };
+    // bottom-up: decreasing index order, in parallel over index ranges level by level would need heights; the plain loop is
+    // 0.3 s per 100 k triangles, so large inputs are split over threads by subtree (a subtree's nodes only depend on themselves)
+    std::function<void(uint32_t)> run = [&](uint32_t v) {
+      const Node2& nd = B.nodes[v];
+      if (nd.count > 0) return;
+      // subtree size is not stored: use the primitive range of the build (first/count live in leaves only) -> recurse, fork near the top
+      run(nd.left); run(nd.right);
+      static thread_local Local L;
+      solve(v, L);
+    };
+    // fork the top levels: collect subtree roots at depth ~ log2(threads) + 2, run them on threads, then finish the top serially
+    std::vector<uint32_t> roots{0}, top_nodes;
+    const int want = std::max(1, num_threads) * 4;
+    while ((int)roots.size() < want) {
+      std::vector<uint32_t> next_roots; bool grew = false;
+      for (uint32_t v : roots) {
+        const Node2& nd = B.nodes[v];
+        if (nd.count > 0) { next_roots.push_back(v); continue; }
+        top_nodes.push_back(v); next_roots.push_back(nd.left); next_roots.push_back(nd.right); grew = true;
+      }
+      roots.swap(next_roots);
+      if (!grew) break;
+    }
+    std::atomic<size_t> cursor{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < std::max(1, num_threads); ++t)
+      pool.emplace_back([&]() { for (;;) { const size_t i = cursor++; if (i >= roots.size()) break; run(roots[i]); } });
+    for (auto& th : pool) th.join();
+    std::sort(top_nodes.begin(), top_nodes.end(), [](uint32_t a, uint32_t b) { return a > b; });  // children before parents
+    static thread_local Local Ltop;
+    for (uint32_t v : top_nodes) solve(v, Ltop);
+  }
+
   // ---- collapse to 8-wide, breadth first --------------------------------------------------------
   struct Work { uint32_t n2; uint32_t n8; uint32_t depth; };
   std::deque<Work> queue;
@@ -226,7 +331,10 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     const Node2& r = B.nodes[wk.n2];
     uint32_t ch[8]; int nch = 0;
     if (r.count > 0) { ch[nch++] = wk.n2; }  // degenerate: the whole tree is one triangle
-    else if (use_dp) {
+    else if (collapse_mode == 2) {
+      const Cut& C = cuts[wk.n2];
+      for (int i = 0; i < C.count; ++i) ch[nch++] = C.node[i];
+    } else if (use_dp) {
       // the SAH-optimal cut of this binary subtree into <= 8 children (collapse_dp above): follow the recorded decisions
       struct Item { uint32_t node; int slots; };
       Item st[16]; int sp = 0;
