@@ -104,3 +104,28 @@ def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
     for (x, y, w, h) in TILES:
         assert bits_equal(film.data[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3]), (x, y)
     assert ref[..., :3].max() > 0.0
+
+
+@pytest.mark.parametrize("width,height", [(1920, 1080), (3840, 2160)])
+def test_bmw_standin_configs_at_film_size(orc, width, height):
+    """BASELINE configs #3 and #5 (the reference ships no BMW scene: the declared stand-in is a 500 k-triangle soup cycling through
+    16 closure recipes, every lobe type): the general k_shade on the whole 1920x1080 / 3840x2160 film at 4 spp, ray accounting,
+    and tiles from all over the film (edge bands included) against the oracle, bit for bit."""
+    from phosphorus_mk2_amd import scenes, xpu
+    xpu.load_library()
+    sc = scenes.multi_material_soup(500_000, width=width, height=height)
+    film, st = xpu.render(sc, spp=SPP, pps=1, depth=9, seed=11, native_sink=True)
+    assert st["camera_samples"] == width * height * SPP and st["tiles"] == ((width + 31) // 32) * ((height + 31) // 32)
+    assert st["rays_closest"] > st["camera_samples"] and st["rays_shadow"] + st["rays_masked"] <= st["rays_closest"]
+    ty = (height // 32) * 32  # the edge band: 1080 = 33 * 32 + 24, 2160 = 67 * 32 + 16
+    tiles = [(0, 0, 32, 32), (width - 32, 0, 32, 32), (width // 2, (height // 64) * 32, 32, 32), (32 * 7, 32 * 5, 32, 32),
+             (0, ty, 32, height - ty), (width - 32, ty, 32, height - ty)]
+    orc.set_tie_rule(1)
+    try:
+        ref, _ = orc.Oracle(sc, spp=SPP).render(rng=orc.RNG_COUNTER, seed=11, threads=16, tiles=tiles)
+    finally:
+        orc.set_tie_rule(0)
+    for (x, y, w, h) in tiles:
+        a, b = film[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3]
+        fin = np.isfinite(b).all(-1)
+        assert np.array_equal(fin, np.isfinite(a).all(-1)) and fin.mean() > 0.99 and bits_equal(a[fin], b[fin]), (x, y)
