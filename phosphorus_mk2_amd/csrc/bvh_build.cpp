@@ -41,6 +41,7 @@ struct Builder2 {
   const float* centroid;  // 3 per prim
   std::vector<uint32_t> idx;
   std::vector<Node2> nodes;
+  const uint64_t* morton = nullptr;  // experiment (PHX_HOST_LBVH=1): idx is sorted by these codes and nodes split at the highest differing bit
   std::atomic<uint32_t> next{0};
   std::atomic<int> spare_threads{0};
 
@@ -52,6 +53,20 @@ struct Builder2 {
     for (uint32_t i = first; i < first + count; ++i) { b.grow(pbox[idx[i]]); cb.grow(centroid + 3 * (size_t)idx[i]); }
     nd.box = b; nd.first = first; nd.count = 0; nd.left = nd.right = 0;
     if (count == 1) { nd.count = 1; return; }
+    if (morton) {  // the split of a linear BVH (what csrc/bvh_gpu.hip builds): where the highest differing bit of the sorted codes flips
+      const uint64_t a = morton[first], z = morton[first + count - 1];
+      uint32_t mid = first + count / 2;
+      if (a != z) {
+        const int bit = 63 - __builtin_clzll(a ^ z);
+        uint32_t lo = first, hi = first + count - 1;  // last index whose bit is 0
+        while (lo < hi) { const uint32_t m = (lo + hi + 1) / 2; if ((morton[m] >> bit) & 1ull) hi = m - 1; else lo = m; }
+        mid = lo + 1;
+      }
+      const uint32_t l = alloc(), r = alloc();
+      nodes[ni].left = l; nodes[ni].right = r;
+      build(l, first, mid - first); build(r, mid, first + count - mid);
+      return;
+    }
     // binned SAH over the three axes
     float best_cost = FLT_MAX; int best_axis = -1, best_bin = -1;
     for (int a = 0; a < 3; ++a) {
@@ -177,6 +192,27 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
   B.nodes.resize(2 * (size_t)n);
   B.next = 1;
   B.spare_threads = std::max(0, num_threads - 1);
+  std::vector<uint64_t> codes;
+  if (getenv("PHX_HOST_LBVH") && atoi(getenv("PHX_HOST_LBVH"))) {  // experiment: the device builder's binary tree, on the host
+    Box cbox; cbox.reset();
+    for (uint32_t i = 0; i < n; ++i) cbox.grow(cen.data() + 3 * (size_t)i);
+    auto spread = [](uint64_t v) { uint64_t r = 0; for (int b = 0; b < 21; ++b) r |= ((v >> b) & 1ull) << (3 * b); return r; };
+    std::vector<uint64_t> key(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      uint64_t q[3];
+      for (int a = 0; a < 3; ++a) {
+        const float ext = cbox.hi[a] - cbox.lo[a];
+        float u = ext > 0.0f ? (cen[3 * (size_t)i + a] - cbox.lo[a]) / ext : 0.0f;
+        u = std::min(std::max(u, 0.0f), 1.0f);
+        q[a] = (uint64_t)std::min(u * 2097152.0f, 2097151.0f);
+      }
+      key[i] = (spread(q[0]) << 2) | (spread(q[1]) << 1) | spread(q[2]);
+    }
+    std::sort(B.idx.begin(), B.idx.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+    codes.resize(n);
+    for (uint32_t i = 0; i < n; ++i) codes[i] = key[B.idx[i]];
+    B.morton = codes.data();
+  }
   B.build(0, 0, n);
 
   // ---- which binary nodes become 8-wide nodes: SAH-optimal collapse by dynamic programming (Ylitie, Karras, Laine: "Efficient
@@ -231,6 +267,7 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     std::vector<float> sub(nn, 0.0f);
     cuts.resize(nn);
     const float CN = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f, CT = 1.0f;  // measured VALU time per node visit : per triangle test
+    static const uint32_t dp_heap_limit = getenv("PHX_DP_HEAP") ? (uint32_t)atoi(getenv("PHX_DP_HEAP")) : 128u;  // experiment: 16 = cuts within 4 levels
     struct Local {
       float best[256][9]; uint8_t split[256][9]; uint8_t done[256][9]; uint32_t node[256];
     };
@@ -258,7 +295,7 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
         if (nd.count > 0) r = areaq(nd.box) * CT;
         else {
           r = areaq(nd.box) * CN + sub[v];  // as ONE slot: an 8-wide node of its own
-          if (j > 1 && h < 128) {
+          if (j > 1 && h < dp_heap_limit) {
             for (int k = 1; k < j; ++k) {
               const float t = best(2 * h, nd.left, k) + best(2 * h + 1, nd.right, j - k);
               if (t < r) { r = t; sp = (uint8_t)k; }
