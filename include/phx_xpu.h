@@ -64,9 +64,10 @@ typedef struct phx_options {
   uint32_t bvh_builder;       /* PHX_BVH_AUTO (default), PHX_BVH_DEVICE_LBVH or PHX_BVH_HOST_SAH: where preprocess builds the tree */
   uint32_t reserved[5];
 } phx_options;
-/* AUTO: binned SAH on the host cores up to 2 M triangles (traces 2-8 % faster, builds 1 M triangles in ~0.6 s), LBVH on the device
- * above (10 M triangles in 0.1 s instead of 7 s, and no slower to trace at that size) — cpu_t::preprocess rebuilds its
- * accelerator on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the interface's cost. */
+/* AUTO: binned SAH on the host cores up to 2 M triangles (ahead by 3-5 % in trace time on mesh-like scenes, builds 1 M triangles
+ * in ~0.6 s), LBVH on the device above (10 M triangles in 0.27 s instead of 7 s, and no slower to trace at that size) —
+ * cpu_t::preprocess rebuilds its accelerator on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the
+ * interface's cost. */
 enum { PHX_BVH_AUTO = 0, PHX_BVH_DEVICE_LBVH = 1, PHX_BVH_HOST_SAH = 2 };
 
 /* ---- scene: what the device reads through scene_t (src/scene.hpp:14-50) --------------- */
@@ -213,6 +214,8 @@ typedef struct phx_stats {
   uint64_t node_block_execs;   /* instrumented: iterations in which at least one lane visited a node */
   uint64_t tri_block_execs;    /* instrumented: iterations in which at least one lane tested a triangle */
   uint64_t refills;            /* instrumented: refill rounds summed over waves */
+  double   bvh_cost_model;     /* modelled traversal cost of the tree in use (the optimal collapse's objective; area units) */
+  uint64_t bvh_built_on_device; /* 1: the tree in use was built on the device */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

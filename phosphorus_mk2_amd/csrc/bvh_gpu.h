@@ -14,6 +14,7 @@ struct GpuBvh {
   uint32_t num_elems;  // elements in use: nodelets + triangle records (material word already filled)
   uint32_t num_nodes, num_tris, depth;
   SceneGrid grid;      // the grid the nodelets' origins are stored on
+  float cost;          // modelled traversal cost of the collapse (sub(root) of k_collapse_dp; 0 if greedy): comparable with Bvh8::cost
 };
 
 // d_abc: 9 floats per primitive (a, b, c) in scene_t::triangles() order, device memory.

@@ -413,9 +413,9 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   HCHK(hipMemcpyAsync(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
   Tree2 T{left, right, first, last, nbox, sorted, (int)n};
   // optimal collapse (PHX_LBVH_COLLAPSE=0: the greedy surface-area expansion)
-  uint32_t* cut = nullptr; uint8_t* cut_count = nullptr;
+  uint32_t* cut = nullptr; uint8_t* cut_count = nullptr; float* sub = nullptr;
   if (!(getenv("PHX_LBVH_COLLAPSE") && atoi(getenv("PHX_LBVH_COLLAPSE")) == 0)) {
-    float* sub = (float*)dalloc(4 * (size_t)n);
+    sub = (float*)dalloc(4 * (size_t)n);
     cut = (uint32_t*)dalloc(4 * 8 * (size_t)n); cut_count = (uint8_t*)dalloc((size_t)n);
     if (!sub || !cut || !cut_count) { std::snprintf(err, errlen, "hipMalloc failed (collapse tables)"); cleanup(); return 1; }
     HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));  // k_fit is done with its arrival flags
@@ -441,6 +441,9 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   }
   HCHK(hipStreamSynchronize(stream));
   if (h_counters[1] != n) { std::snprintf(err, errlen, "device BVH builder lost triangles (%u of %u)", h_counters[1], n); cleanup(); return 1; }
+  float cost = 0.0f;
+  if (sub) HCHK(hipMemcpy(&cost, sub, 4, hipMemcpyDeviceToHost));
+  out->cost = cost;
   keep_output = true;
   out->pool = pool; out->num_elems = h_counters[0]; out->num_tris = h_counters[1]; out->num_nodes = h_counters[3]; out->depth = depth; out->grid = grid;
   cleanup();

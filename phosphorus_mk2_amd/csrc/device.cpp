@@ -94,6 +94,7 @@ struct phx_device {
   phx_stats stats{};
   TracePlan plan{};
   uint64_t paths_in_flight = 0;
+  double bvh_cost_model = 0; uint32_t bvh_built_on_device = 0;
   std::vector<hipEvent_t> events; size_t events_used = 0;
   std::vector<std::pair<size_t, int>> timed;  // (event index of start, kind 0 closest / 1 shadow / 2 other)
 
@@ -308,27 +309,37 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   int rc;
   if ((rc = d->d_prim_material.upload(prim_material))) return rc;
   const auto t_bvh0 = std::chrono::steady_clock::now();
-  uint32_t bvh_depth = 0; size_t bvh_node_count = 0, bvh_elems = 0;
-  SceneGrid bvh_grid{};
-  uint32_t builder = d->opt.bvh_builder;
-  if (builder == PHX_BVH_AUTO) builder = prim_material.size() > 2000000u ? PHX_BVH_DEVICE_LBVH : PHX_BVH_HOST_SAH;
-  if (builder == PHX_BVH_DEVICE_LBVH) {
+  // PHX_BVH_AUTO: binned SAH on the host cores up to 2 M triangles, Morton LBVH on the device above (10 M: 0.27 s instead of 7 s).
+  // Both trees get the optimal 8-wide collapse, whose objective (bvh_cost_model in the stats) was tried as the way to choose
+  // between them and does not rank them: it calls the host tree 6-13 % cheaper everywhere, while measured trace times differ by
+  // -5..+5 % (host ahead on mesh-like scenes, device ahead on the 1 M soup; profiles/r02_l_auto_probe.log).
+  const uint32_t builder = d->opt.bvh_builder;
+  const uint32_t ntri = (uint32_t)prim_material.size();
+  if (builder > PHX_BVH_HOST_SAH) return fail(PHX_ERR_ARG, "unknown bvh_builder");
+  const bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri <= 2000000u);
+  const bool want_device = !want_host;
+  GpuBvh g{};
+  if (want_device) {
     // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
     DevBuf<float> d_abc;
     if ((rc = d_abc.upload(abc))) return rc;
-    GpuBvh g{}; char msg[256] = {0};
-    if (build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, (uint32_t)prim_material.size(), &g, msg, sizeof(msg)))
+    char msg[256] = {0};
+    if (build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg)))
       return fail(PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
-    d->d_pool.adopt(g.pool, g.num_elems);
-    bvh_depth = g.depth; bvh_node_count = g.num_nodes; bvh_elems = g.num_elems; bvh_grid = g.grid;
-  } else if (builder == PHX_BVH_HOST_SAH) {
+  }
+  uint32_t bvh_depth = 0; size_t bvh_node_count = 0, bvh_elems = 0;
+  SceneGrid bvh_grid{};
+  if (want_host) {
     Bvh8 bvh;
     const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    build_bvh8(abc.data(), (uint32_t)prim_material.size(), bvh, threads, prim_material.data());
+    build_bvh8(abc.data(), ntri, bvh, threads, prim_material.data());
     if ((rc = d->d_pool.upload(bvh.pool))) return rc;
     bvh_depth = bvh.depth; bvh_node_count = bvh.num_nodes; bvh_elems = bvh.pool.size(); bvh_grid = bvh.grid;
+    d->bvh_cost_model = bvh.cost; d->bvh_built_on_device = 0;
   } else {
-    return fail(PHX_ERR_ARG, "unknown bvh_builder");
+    d->d_pool.adopt(g.pool, g.num_elems);
+    bvh_depth = g.depth; bvh_node_count = g.num_nodes; bvh_elems = g.num_elems; bvh_grid = g.grid;
+    d->bvh_cost_model = g.cost; d->bvh_built_on_device = 1;
   }
   const auto t_bvh1 = std::chrono::steady_clock::now();
   // k_trace / k_trace_rays keep one pending sibling group per level and lane in LDS (bvh8.h: PHX_MAX_BVH_DEPTH)
@@ -411,6 +422,7 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   out->trace_block = d->plan.block; out->trace_ntop = d->plan.ntop; out->trace_levels = d->plan.levels;
   out->trace_waves_per_cu = (uint64_t)d->plan.wg_per_cu * (d->plan.block / 64u); out->bvh_depth = d->scene.stack_levels;
   out->paths_in_flight = d->paths_in_flight;
+  out->bvh_cost_model = d->bvh_cost_model; out->bvh_built_on_device = d->bvh_built_on_device;
   return PHX_OK;
 }
 

@@ -344,3 +344,41 @@ def multi_material_soup(n, seed=1234, width=1280, height=720):
     s = soup(n, seed, width, height, materials=mats)
     s.name = f"zoo_soup{n}"
     return s
+
+
+def showroom(n, seed=5, width=1280, height=720, materials=None):
+    """A non-uniform, mesh-like scene (connected surfaces, three orders of magnitude of triangle sizes): a closed grey room with a
+    ceiling light holding 24 lat/long-tessellated spheres of radius 0.04..0.55 whose triangle counts are NOT proportional to their
+    area (the smallest sphere gets as many triangles as the largest: "teapot in a stadium"), about n triangles in total.  Used to
+    check both tree builders — and PHX_BVH_AUTO's choice between them — on something that is not the uniform soup of SURVEY §8(d).
+    With `materials` the spheres cycle through that list (material 0 stays the room's)."""
+    rng = np.random.default_rng(seed)
+    mats = [diffuse(0.73, 0.73, 0.73)] + (list(materials) if materials else [diffuse(0.6, 0.3, 0.2), diffuse(0.2, 0.5, 0.7)])
+    nm = len(mats)
+    mats.append(emitter(*LE))
+    X0, X1, Y0, Y1, Z0, Z1 = -2.0, 2.0, -1.0, 1.6, -4.6, -0.4
+    meshes = [
+        _quad((X0, Y0, Z1), (X1, Y0, Z1), (X1, Y0, Z0), (X0, Y0, Z0), 0),   # floor
+        _quad((X0, Y0, Z0), (X1, Y0, Z0), (X1, Y1, Z0), (X0, Y1, Z0), 0),   # back
+        _quad((X0, Y0, Z1), (X0, Y0, Z0), (X0, Y1, Z0), (X0, Y1, Z1), 0),   # left
+        _quad((X1, Y0, Z0), (X1, Y0, Z1), (X1, Y1, Z1), (X1, Y1, Z0), 0),   # right
+        _quad((X0, Y1, Z0), (X1, Y1, Z0), (X1, Y1, Z1), (X0, Y1, Z1), 0),   # ceiling
+        _quad((-0.8, Y1 - 0.01, -1.7), (-0.8, Y1 - 0.01, -3.3), (0.8, Y1 - 0.01, -3.3), (0.8, Y1 - 0.01, -1.7), nm),
+    ]
+    nspheres = 24
+    per = max(8, int(n) // nspheres)
+    for k in range(nspheres):
+        radius = float(0.04 * (0.55 / 0.04) ** rng.random())
+        centre = np.array([rng.uniform(X0 + radius, X1 - radius), rng.uniform(Y0 + radius, Y1 - 0.3 - radius), rng.uniform(Z0 + radius, -1.2 - radius)])
+        rings = max(2, int(round(np.sqrt(per / 4.0))))          # 2*rings*segs triangles with segs = 2*rings
+        segs = 2 * rings
+        th = np.linspace(0.0, np.pi, rings + 1)[:, None]
+        ph = np.linspace(0.0, 2.0 * np.pi, segs + 1)[None, :-1]
+        p = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], -1)  # (rings+1, segs, 3)
+        v = (centre + radius * p.reshape(-1, 3)).astype(np.float32)
+        i = np.arange(rings)[:, None]; j = np.arange(segs)[None, :]
+        a = (i * segs + j).ravel(); b = (i * segs + (j + 1) % segs).ravel()
+        c = ((i + 1) * segs + j).ravel(); d = ((i + 1) * segs + (j + 1) % segs).ravel()
+        f = np.concatenate([np.stack([a, b, d], 1), np.stack([a, d, c], 1)]).astype(np.uint32)  # outward-facing; the pole rows hold slivers of zero area
+        meshes.append(MeshDesc(vertices=v, faces=f, sets=[(1 + k % (nm - 1), np.arange(len(f), dtype=np.uint32))]))
+    return SceneDesc(meshes, mats, CameraDesc(width, height, 1.9), name=f"showroom{n}")

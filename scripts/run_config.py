@@ -16,7 +16,7 @@ import numpy as np  # noqa: E402
 from phosphorus_mk2_amd import scenes, xpu  # noqa: E402
 
 p = argparse.ArgumentParser()
-p.add_argument("--scene", default="soup", choices=["soup", "zoo", "cornell"])
+p.add_argument("--scene", default="soup", choices=["soup", "zoo", "cornell", "showroom"])
 p.add_argument("--triangles", type=int, default=100000)
 p.add_argument("--width", type=int, default=1280)
 p.add_argument("--height", type=int, default=720)
@@ -31,6 +31,8 @@ if a.scene == "soup":
     sc = scenes.soup(a.triangles, width=a.width, height=a.height)
 elif a.scene == "zoo":
     sc = scenes.multi_material_soup(a.triangles, width=a.width, height=a.height)
+elif a.scene == "showroom":
+    sc = scenes.showroom(a.triangles, width=a.width, height=a.height)
 else:
     sc = scenes.cornell(a.width, a.height)
 t_scene = time.time() - t0
@@ -51,6 +53,6 @@ for _ in range(a.frames):
 rays = st["rays_closest"] + st["rays_shadow"]
 print(json.dumps({"scene": sc.name, "triangles": sc.num_triangles, "film": [a.width, a.height], "spp": a.spp, "rank": a.rank, "world": a.world,
                   "tiles": len(tiles), "scene_gen_s": t_scene, "preprocess_s": t_pre, "frame_s": best, "rays": rays, "Mrays_per_s": rays / best / 1e6,
-                  "builder": a.builder, "bvh_build_ms": st["bvh_build_ms"], "plan": [st["trace_block"], st["trace_ntop"], st["trace_levels"]], "trace_ms": st["trace_ms"], "shade_ms": st["shade_ms"], "bvh_MB": st["bvh_bytes"] / 1e6, "film_mean": float(film.data[..., :3].mean()),
+                  "builder": a.builder, "bvh_cost_model": st["bvh_cost_model"], "bvh_built_on_device": st["bvh_built_on_device"], "bvh_depth": st["bvh_depth"], "bvh_build_ms": st["bvh_build_ms"], "plan": [st["trace_block"], st["trace_ntop"], st["trace_levels"]], "trace_ms": st["trace_ms"], "shade_ms": st["shade_ms"], "bvh_MB": st["bvh_bytes"] / 1e6, "film_mean": float(film.data[..., :3].mean()),
                   "finite": bool(np.isfinite(film.data).all())}))
 dev.close()

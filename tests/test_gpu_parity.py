@@ -313,6 +313,36 @@ def test_stress_geometry(xpu, orc, builder):
     assert max_pixel_l2(film, ref) < L2_TOL and bits_equal(film[..., :3], ref[..., :3])
 
 
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_showroom_meshes_match_oracle(xpu, orc, builder):
+    """connected, indexed meshes with shared vertices (every ray that leaves a sphere's surface starts ON an edge or vertex of
+    its neighbours), zero-area pole slivers, three orders of magnitude of triangle size, inside a closed room: closest and
+    shadow rays bit for bit against brute force, then the film — with glass and glossy spheres — against the oracle"""
+    from phosphorus_mk2_amd import scenes
+    from test_host_bvh8 import stress_rays
+    sc = scenes.showroom(20000, width=160, height=96, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])
+    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder=builder))[0]
+    dev.preprocess(sc)
+    O = orc.Oracle(sc, spp=1)
+    o, d, tm = stress_rays(sc, 6000, 11)
+    g = dev.trace(o, d, tm)
+    orc.set_tie_rule(1)
+    try:
+        r = O.trace(o, d, tm, brute=True)
+    finally:
+        orc.set_tie_rule(0)
+    assert g["hit"].sum() > 3000
+    assert np.array_equal(g["hit"], r["hit"]) and np.array_equal(g["prim"], r["prim"]) and bits_equal(g["t"], r["t"])
+    assert bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    tm2 = np.full(len(tm), 0.8, np.float32)
+    assert np.array_equal(dev.trace(o, d, tm2, shadow=True)["hit"], O.trace(o, d, tm2, shadow=True, brute=True)["hit"])
+    dev.close()
+    film, st = xpu.render(sc, spp=8, seed=6, bvh_builder=builder)
+    ref, ost = orc.Oracle(sc, spp=8, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=6, threads=8)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"]
+    assert max_pixel_l2(film, ref) < L2_TOL and bits_equal(film[..., :3], ref[..., :3])
+
+
 def _room_scene():
     """the scene examples/render_room.c builds in C, through the Python mirror"""
     from phosphorus_mk2_amd import abi, scenes

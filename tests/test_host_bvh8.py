@@ -96,6 +96,24 @@ def test_stress_geometry_equals_brute_force(host_bvh8, orc):
     host_bvh8.hb8_free(h)
 
 
+def test_showroom_meshes_equal_brute_force(host_bvh8, orc):
+    """indexed meshes with shared vertices, pole slivers of zero area and very different triangle sizes (scenes.showroom)"""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.showroom(20000, width=32, height=32)
+    abc = tri_abc(sc)
+    h = host_bvh8.hb8_build(fp(abc), len(abc), 4)
+    o, d, tm = stress_rays(sc, 6000, 11)
+    g = trace(host_bvh8, h, o, d, tm)
+    orc.set_tie_rule(1)
+    try:
+        r = orc.Oracle(sc, spp=1).trace(o, d, tm, brute=True)
+    finally:
+        orc.set_tie_rule(0)
+    assert (g["prim"] != 0xffffffff).sum() > 3000
+    assert np.array_equal(g["prim"], r["prim"]) and bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
+    host_bvh8.hb8_free(h)
+
+
 def test_degenerate_inputs(host_bvh8):
     # empty scene: a root that hits nothing; one triangle; coincident triangles (identical centroids)
     h = host_bvh8.hb8_build(fp(np.zeros((0, 9), np.float32)), 0, 1)
