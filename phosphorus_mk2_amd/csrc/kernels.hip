@@ -138,6 +138,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #if PHX_COUNT
   uint32_t cnt_lds[2] = {0, 0}, cnt_mem[2] = {0, 0}, cnt_tri[2] = {0, 0};  // instrumented build: this lane's traversal work
   uint32_t cnt_iter = 0, cnt_nb = 0, cnt_tb = 0, cnt_refill = 0;              // ... and the wave's (wave-uniform)
+  uint32_t cnt_idle = 0, cnt_pend = 0;
 #endif
   for (;;) {
     // ---- refill idle lanes from the workgroup's cursors
@@ -202,6 +203,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #if PHX_COUNT
     ++cnt_iter;
     if (__ballot(active && th == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
+    cnt_idle += (uint32_t)__popcll(__ballot(!active)); cnt_pend += (uint32_t)__popcll(__ballot(active && th != 0));
 #endif
 #pragma unroll
     for (int step = 0; step < PHX_STEPS_PER_REFILL; ++step)
@@ -294,6 +296,8 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     atomicAdd(&pb.stats->wave_iters, (unsigned long long)cnt_iter);
     atomicAdd(&pb.stats->node_block_execs, (unsigned long long)cnt_nb);
     atomicAdd(&pb.stats->refills, (unsigned long long)cnt_refill);
+    atomicAdd(&pb.stats->idle_lane_iters, (unsigned long long)cnt_idle);
+    atomicAdd(&pb.stats->tri_pending_lane_iters, (unsigned long long)cnt_pend);
   }
 #endif
 }
