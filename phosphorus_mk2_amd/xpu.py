@@ -311,12 +311,12 @@ class HipDevice:
             pass
 
 
-def render_on(devices, scene_desc, seed=1, normals=False, tile_size=32, native_sink=True):
+def render_on(devices, scene_desc, seed=1, normals=False, tile_size=32, native_sink=True, rank=0, world=1):
     """The reference's frame on SEVERAL devices in one process (src/core.cpp:103-115): every device is started on the SAME tile
     queue and the SAME film and joined in turn; no collective.  `devices` must have been preprocessed with `scene_desc`.
     Returns (film array, [stats per device])."""
     W, H = scene_desc.camera.width, scene_desc.camera.height
-    tiles = Tiles.make(W, H, tile_size)
+    tiles = Tiles.make(W, H, tile_size, rank, world)
     film = Film(W, H, 4, normals)
     for d in devices:
         d.start(scene_desc, FrameState(seed, tiles, film, native_sink=native_sink))

@@ -14,4 +14,8 @@ run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT
 run grbm GRBM_GUI_ACTIVE
+run ta1 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+run tcc TCC_HIT TCC_MISS
+run td TD_TD_BUSY_sum TD_TC_STALL_sum
 echo "profile $TAG done"
