@@ -8,14 +8,24 @@ from phosphorus_mk2_amd import scenes, xpu
 from oracle import oracle as orc
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-what = sys.argv[2] if len(sys.argv) > 2 else "100000"   # triangle count of the soup, or "cornell" (BASELINE config #1: 256x256)
-sc = scenes.cornell(256, 256) if what == "cornell" else scenes.soup(int(what), seed=1234, width=1280, height=720)
-t0 = time.time(); film, st = xpu.render(sc, spp=spp, pps=1, depth=9, seed=1, native_sink=True); t_gpu = time.time() - t0
-out = {"scene": sc.name, "spp": spp, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]]}
+what = sys.argv[2] if len(sys.argv) > 2 else "100000"   # triangle count of the soup, "cornell" (BASELINE config #1: 256x256), "zoo:N" (BMW stand-in, 1920x1080), "showroom:N"
+builder = sys.argv[3] if len(sys.argv) > 3 else "auto"
+if what == "cornell":
+    sc = scenes.cornell(256, 256)
+elif what.startswith("zoo:"):
+    sc = scenes.multi_material_soup(int(what[4:]), width=1920, height=1080)
+elif what.startswith("showroom:"):
+    sc = scenes.showroom(int(what[9:]), width=1280, height=720, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])
+else:
+    sc = scenes.soup(int(what), seed=1234, width=1280, height=720)
+import bench
+threads = max(1, int(bench.host_cpus()[2]))  # the CPU share of this job: more oracle threads than that lose to context switches
+t0 = time.time(); film, st = xpu.render(sc, spp=spp, pps=1, depth=9, seed=1, native_sink=True, bvh_builder=builder); t_gpu = time.time() - t0
+out = {"scene": sc.name, "spp": spp, "builder": builder, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]], "oracle_threads": threads}
 for rule in (1, 0):
     orc.set_tie_rule(rule)
     t0 = time.time()
-    ref, ost = orc.Oracle(sc, spp=spp, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=1, threads=os.cpu_count())
+    ref, ost = orc.Oracle(sc, spp=spp, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=1, threads=threads)
     d = film[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64)
     out["device_tie_rule" if rule else "reference_tie_rule"] = {
         "oracle_s": time.time() - t0, "oracle_rays": [ost["rays_closest"], ost["rays_shadow"], ost["rays_masked"]],
