@@ -216,6 +216,7 @@ typedef struct phx_stats {
   uint64_t refills;            /* instrumented: refill rounds summed over waves */
   uint64_t idle_lane_iters;    /* instrumented: lanes without a ray at the node block, summed over iterations */
   uint64_t tri_pending_lane_iters; /* instrumented: lanes that sit out the node block because triangles of their last node are pending */
+  uint64_t stack_pushes[8];    /* instrumented: pushes onto the per-lane stack of pending sibling groups, by the depth they land at (7 = 7 and deeper) */
   double   bvh_cost_model;     /* modelled traversal cost of the tree in use (the optimal collapse's objective; area units) */
   uint64_t bvh_built_on_device; /* 1: the tree in use was built on the device */
 } phx_stats;

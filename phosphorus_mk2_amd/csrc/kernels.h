@@ -51,7 +51,8 @@ struct DevStats {
   unsigned long long node_visits_lds[2], node_visits_mem[2], tri_tests[2];
   // wave-level: loop iterations, executions of the node block / the triangle block (a block runs when ANY lane needs it)
   unsigned long long wave_iters, node_block_execs, tri_block_execs, refills;
-  unsigned long long idle_lane_iters, tri_pending_lane_iters;  // instrumented: lanes without a ray / with triangles still pending at the node block, summed over iterations
+  unsigned long long idle_lane_iters, tri_pending_lane_iters;
+  unsigned long long stack_pushes[8];  // instrumented: pushes onto the per-lane group stack by the depth they land at (7 = 7 and deeper)  // instrumented: lanes without a ray / with triangles still pending at the node block, summed over iterations
 };
 
 struct PassBuffers {

@@ -114,6 +114,18 @@ struct LdsStack {
 #ifndef PHX_STEPS_PER_REFILL
 #define PHX_STEPS_PER_REFILL 1
 #endif
+// PHX_RUNAHEAD: a lane whose last node left more than one triangle to test does not sit out the following node blocks (8.9 of 64
+// lanes per iteration at 100 k triangles): it keeps visiting nodes while the triangles drain one per iteration from a two-entry
+// queue (tq/tb: bits | valid byte << 8 and child base of the node they belong to).  Results do not depend on the order of tests.
+#ifndef PHX_RUNAHEAD
+#define PHX_RUNAHEAD 0
+#endif
+#ifndef PHX_PROBE_VALU
+#define PHX_PROBE_VALU 0
+#endif
+#ifndef PHX_PROBE_VMEM
+#define PHX_PROBE_VMEM 0
+#endif
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
 struct DynQueue {            // DYN: the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
@@ -131,6 +143,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
   float tbest = 0.f, hu = 0.f, hv = 0.f;
   uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, th = 0, path = 0;
+#if PHX_RUNAHEAD
+  uint32_t tb = 0, tq2 = 0, tb2 = 0;  // th = first queue entry (bits | valid << 8), tb its base; tq2 / tb2 the second
+#endif
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
@@ -139,6 +154,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   uint32_t cnt_lds[2] = {0, 0}, cnt_mem[2] = {0, 0}, cnt_tri[2] = {0, 0};  // instrumented build: this lane's traversal work
   uint32_t cnt_iter = 0, cnt_nb = 0, cnt_tb = 0, cnt_refill = 0;              // ... and the wave's (wave-uniform)
   uint32_t cnt_idle = 0, cnt_pend = 0;
+  uint32_t cnt_push[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (;;) {
     // ---- refill idle lanes from the workgroup's cursors
@@ -192,6 +208,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           }
           hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
           ng_base = 0; ng_hits = 0x80000000u; th = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
+#if PHX_RUNAHEAD
+          tq2 = 0;
+#endif
           any = phase == 0u;
           active = true;
         }
@@ -202,17 +221,31 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     if (!__ballot(active)) break;
 #if PHX_COUNT
     ++cnt_iter;
+#if PHX_RUNAHEAD
+    if (__ballot(active && tq2 == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
+    cnt_idle += (uint32_t)__popcll(__ballot(!active)); cnt_pend += (uint32_t)__popcll(__ballot(active && !(tq2 == 0 && ng_hits > 0x00ffffffu)));
+#else
     if (__ballot(active && th == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
     cnt_idle += (uint32_t)__popcll(__ballot(!active)); cnt_pend += (uint32_t)__popcll(__ballot(active && th != 0));
+#endif
 #endif
 #pragma unroll
     for (int step = 0; step < PHX_STEPS_PER_REFILL; ++step)
     if (active) {
       // ---- one node visit
+#if PHX_RUNAHEAD
+      if (tq2 == 0 && ng_hits > 0x00ffffffu) {
+#else
       if (th == 0 && ng_hits > 0x00ffffffu) {
+#endif
         const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
         const uint32_t rest = ng_hits & ~(1u << bit);
-        if (rest > 0x00ffffffu) { stack_base[sp * BLOCK] = make_uint2(ng_base, rest); ++sp; }
+        if (rest > 0x00ffffffu) {
+#if PHX_COUNT
+          ++cnt_push[sp < 7 ? sp : 7];
+#endif
+          stack_base[sp * BLOCK] = make_uint2(ng_base, rest); ++sp;
+        }
         const uint32_t slot = (bit - 24u) ^ r.oct_inv;
         const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
         uint32_t w[16];
@@ -233,23 +266,53 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #pragma unroll
           for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
         }
+#if PHX_PROBE_VMEM
+        // sensitivity probe (never in the product build): PHX_PROBE_VMEM more 16-byte loads per node visit, from the neighbouring element
+        if (!in_lds) {
+          const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)(ni ^ 1u) * 4u;
+#pragma unroll
+          for (int k = 0; k < PHX_PROBE_VMEM; ++k) { const uint4 v = s4[k]; w[2] ^= (v.x ^ v.y ^ v.z ^ v.w) & (refill_min >> 31); }
+        }
+#endif
 #if PHX_PERM_LUT
-        const uint32_t hm = node_hitmask(w, sc.grid, r, tbest, [&](uint32_t m) { return (uint32_t)perm_lut[(r.oct_inv << 8) | m]; });
+        uint32_t hm = node_hitmask(w, sc.grid, r, tbest, [&](uint32_t m) { return (uint32_t)perm_lut[(r.oct_inv << 8) | m]; });
 #else
-        const uint32_t hm = node_hitmask(w, sc.grid, r, tbest);
+        uint32_t hm = node_hitmask(w, sc.grid, r, tbest);
+#endif
+#if PHX_PROBE_VALU
+        {  // sensitivity probe (never in the product build): PHX_PROBE_VALU more v_fma_f32 per node visit
+          float x = tbest;
+#pragma unroll
+          for (int k = 0; k < PHX_PROBE_VALU; ++k) x = __builtin_fmaf(x, 0.99999f, 1.0e-3f);
+          hm ^= f2u(x) & (refill_min >> 31);
+        }
 #endif
         ng_base = w[3];                // the children of the node just visited: nodelets and triangle records, in slot order
         ng_hits = hm & 0xff0000ffu;    // pending inner children | valid mask
+#if PHX_RUNAHEAD
+        if (hm & 0x00ff0000u) {        // triangles to test: into the first free queue entry
+          const uint32_t nq = ((hm >> 16) & 0xffu) | ((hm & 0xffu) << 8);
+          if (th == 0) { th = nq; tb = w[3]; } else { tq2 = nq; tb2 = w[3]; }
+        }
+#else
         th = (hm >> 16) & 0xffu;       // pending triangles, by slot
+#endif
       }
       // ---- one triangle test (ng_base / the valid byte of ng_hits still belong to the node whose triangles are pending)
 #if PHX_COUNT
       if (th != 0 && lane == (uint32_t)__ffsll((long long)__ballot(th != 0)) - 1u) ++cnt_tb;
 #endif
       if (th != 0) {
+#if PHX_RUNAHEAD
+        const uint32_t k = 31u - (uint32_t)__clz((int)(th & 0xffu));
+        th &= ~(1u << k);
+        const uint32_t ti = tb + (uint32_t)__popc((th >> 8) & ~(0xffffffffu << k));
+        if ((th & 0xffu) == 0) { th = tq2; tb = tb2; tq2 = 0; }  // entry used up: the second one moves up
+#else
         const uint32_t k = 31u - (uint32_t)__clz((int)th);
         th &= ~(1u << k);
         const uint32_t ti = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << k));
+#endif
         const uint4* t4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ti * 4u;
         const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2];  // three of the record's four words: v0, e0, e1, prim
         TriRec T;
@@ -266,7 +329,11 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         }
       }
       // ---- pop the next group, or finish the ray
+#if PHX_RUNAHEAD
+      if (active && ng_hits <= 0x00ffffffu && (sp != 0 || th == 0)) {  // the next group is popped while triangles are still queued
+#else
       if (active && th == 0 && ng_hits <= 0x00ffffffu) {
+#endif
         if (sp == 0) {
           if (any) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
             const float4 cc = pb.sc[idx];
@@ -291,6 +358,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     atomicAdd(&pb.stats->node_visits_mem[k], (unsigned long long)cnt_mem[k]);
     atomicAdd(&pb.stats->tri_tests[k], (unsigned long long)cnt_tri[k]);
   }
+  for (int k = 0; k < 8; ++k) if (cnt_push[k]) atomicAdd(&pb.stats->stack_pushes[k], (unsigned long long)cnt_push[k]);
   if (cnt_tb) atomicAdd(&pb.stats->tri_block_execs, (unsigned long long)cnt_tb);  // counted by the first lane that had a triangle
   if (lane == 0) {
     atomicAdd(&pb.stats->wave_iters, (unsigned long long)cnt_iter);

@@ -24,5 +24,6 @@ rays = st["rays_closest"] + st["rays_shadow"]
 nv = sum(st["node_visits_lds"]) + sum(st["node_visits_mem"]); tt = sum(st["tri_tests"])
 out["wave"] = {"iterations": st["wave_iters"], "node_block_execs": st["node_block_execs"], "tri_block_execs": st["tri_block_execs"], "refills": st["refills"], "idle_lanes_per_iteration": st["idle_lane_iters"] / max(1, st["wave_iters"]), "tri_pending_lanes_per_iteration": st["tri_pending_lane_iters"] / max(1, st["wave_iters"]),
                "lanes_per_node_block": nv / max(1, st["node_block_execs"]), "lanes_per_tri_block": tt / max(1, st["tri_block_execs"]),
-               "iterations_per_ray_x64": st["wave_iters"] * 64 / rays}
+               "iterations_per_ray_x64": st["wave_iters"] * 64 / rays,
+               "stack_pushes_per_ray_by_depth": [x / rays for x in st["stack_pushes"]]}
 print(json.dumps(out))
