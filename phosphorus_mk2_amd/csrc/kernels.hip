@@ -114,12 +114,7 @@ struct LdsStack {
 #ifndef PHX_STEPS_PER_REFILL
 #define PHX_STEPS_PER_REFILL 1
 #endif
-// PHX_RUNAHEAD: a lane whose last node left more than one triangle to test does not sit out the following node blocks (8.9 of 64
-// lanes per iteration at 100 k triangles): it keeps visiting nodes while the triangles drain one per iteration from a two-entry
-// queue (tq/tb: bits | valid byte << 8 and child base of the node they belong to).  Results do not depend on the order of tests.
-#ifndef PHX_RUNAHEAD
-#define PHX_RUNAHEAD 0
-#endif
+// Sensitivity probes (profiles/README.md), never in the product build: extra FMAs / extra 16-byte loads per node visit.
 #ifndef PHX_PROBE_VALU
 #define PHX_PROBE_VALU 0
 #endif
@@ -143,9 +138,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
   float tbest = 0.f, hu = 0.f, hv = 0.f;
   uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, th = 0, path = 0;
-#if PHX_RUNAHEAD
-  uint32_t tb = 0, tq2 = 0, tb2 = 0;  // th = first queue entry (bits | valid << 8), tb its base; tq2 / tb2 the second
-#endif
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
@@ -208,9 +200,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           }
           hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
           ng_base = 0; ng_hits = 0x80000000u; th = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
-#if PHX_RUNAHEAD
-          tq2 = 0;
-#endif
           any = phase == 0u;
           active = true;
         }
@@ -221,23 +210,14 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     if (!__ballot(active)) break;
 #if PHX_COUNT
     ++cnt_iter;
-#if PHX_RUNAHEAD
-    if (__ballot(active && tq2 == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
-    cnt_idle += (uint32_t)__popcll(__ballot(!active)); cnt_pend += (uint32_t)__popcll(__ballot(active && !(tq2 == 0 && ng_hits > 0x00ffffffu)));
-#else
     if (__ballot(active && th == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
     cnt_idle += (uint32_t)__popcll(__ballot(!active)); cnt_pend += (uint32_t)__popcll(__ballot(active && th != 0));
-#endif
 #endif
 #pragma unroll
     for (int step = 0; step < PHX_STEPS_PER_REFILL; ++step)
     if (active) {
       // ---- one node visit
-#if PHX_RUNAHEAD
-      if (tq2 == 0 && ng_hits > 0x00ffffffu) {
-#else
       if (th == 0 && ng_hits > 0x00ffffffu) {
-#endif
         const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
         const uint32_t rest = ng_hits & ~(1u << bit);
         if (rest > 0x00ffffffu) {
@@ -289,30 +269,16 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #endif
         ng_base = w[3];                // the children of the node just visited: nodelets and triangle records, in slot order
         ng_hits = hm & 0xff0000ffu;    // pending inner children | valid mask
-#if PHX_RUNAHEAD
-        if (hm & 0x00ff0000u) {        // triangles to test: into the first free queue entry
-          const uint32_t nq = ((hm >> 16) & 0xffu) | ((hm & 0xffu) << 8);
-          if (th == 0) { th = nq; tb = w[3]; } else { tq2 = nq; tb2 = w[3]; }
-        }
-#else
         th = (hm >> 16) & 0xffu;       // pending triangles, by slot
-#endif
       }
       // ---- one triangle test (ng_base / the valid byte of ng_hits still belong to the node whose triangles are pending)
 #if PHX_COUNT
       if (th != 0 && lane == (uint32_t)__ffsll((long long)__ballot(th != 0)) - 1u) ++cnt_tb;
 #endif
       if (th != 0) {
-#if PHX_RUNAHEAD
-        const uint32_t k = 31u - (uint32_t)__clz((int)(th & 0xffu));
-        th &= ~(1u << k);
-        const uint32_t ti = tb + (uint32_t)__popc((th >> 8) & ~(0xffffffffu << k));
-        if ((th & 0xffu) == 0) { th = tq2; tb = tb2; tq2 = 0; }  // entry used up: the second one moves up
-#else
         const uint32_t k = 31u - (uint32_t)__clz((int)th);
         th &= ~(1u << k);
         const uint32_t ti = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << k));
-#endif
         const uint4* t4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ti * 4u;
         const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2];  // three of the record's four words: v0, e0, e1, prim
         TriRec T;
@@ -329,11 +295,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         }
       }
       // ---- pop the next group, or finish the ray
-#if PHX_RUNAHEAD
-      if (active && ng_hits <= 0x00ffffffu && (sp != 0 || th == 0)) {  // the next group is popped while triangles are still queued
-#else
       if (active && th == 0 && ng_hits <= 0x00ffffffu) {
-#endif
         if (sp == 0) {
           if (any) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
             const float4 cc = pb.sc[idx];
