@@ -308,15 +308,18 @@ PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3&
 }
 
 // bsdf_t::f, src/bsdf.cpp:113-131
-template <bool DIFFUSE_ONLY = false>
+// MAXL = 1: the caller guarantees num_lobes <= 1; every lobe index is then the constant 0, so a material assembled in registers
+// (k_shade<2>: DevMatLite) never has to be addressed dynamically.  Same statements, same order, same results.
+template <bool DIFFUSE_ONLY = false, int MAXL = 8>
 PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) {
   v3 out(0.0f);
   if (m.num_lobes == 0) return out;
   const Frame fr(n);
   const float atl = dot(n, wi);
   const bool reflect = atl * dot(n, wo) > 0.0f;
-  for (uint32_t i = 0; i < m.num_lobes; ++i) {
-    const DevLobe& p = m.lobes[i];
+  const uint32_t nl = MAXL == 1 ? 1u : m.num_lobes;
+  for (uint32_t i = 0; i < nl; ++i) {
+    const DevLobe& p = m.lobes[MAXL == 1 ? 0u : i];
     float ignored;
     const float e = lobe_eval<DIFFUSE_ONLY>(p, n, fr, wi, wo, m.sheen_L5, ignored);
     if ((reflect && (p.flags & B_REFLECT)) || (!reflect && (p.flags & B_TRANSMIT))) {
@@ -328,17 +331,18 @@ PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) 
 }
 
 // bsdf_t::sample, src/bsdf.cpp:133-248.  Returns f (already weighted); pdf == 0 terminates.
-template <bool DIFFUSE_ONLY = false>
+template <bool DIFFUSE_ONLY = false, int MAXL = 8>
 PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
   pdf = 0.0f; sample_flags = 0; wo = v3(0.0f);
-  const uint32_t lobes = m.num_lobes;
+  const uint32_t lobes = MAXL == 1 ? (m.num_lobes ? 1u : 0u) : m.num_lobes;
   if (lobes == 0) return v3(0.0f);
   const float fl = (float)lobes;
   uint32_t index = (uint32_t)floorf(u1 * fl);
   if (index > lobes - 1) index = lobes - 1;
+  if (MAXL == 1) index = 0;  // what the two lines above compute for lobes == 1 and u1 in [0, 1)
   const float one_minus_epsilon = 1.0f - FLT_EPSILON;
   const float u = fminf(u1 * fl - (float)index, one_minus_epsilon);
-  const DevLobe& p = m.lobes[index];
+  const DevLobe& p = m.lobes[MAXL == 1 ? 0u : index];
   const Frame fr(n);
   float res = 0.0f;
   bool pdf_set = false;
@@ -428,7 +432,7 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, con
   if (pdf == 0.0f) return v3(0.0f);
   v3 result = v3(res) * v3(p.wx, p.wy, p.wz);
   int matched = 1;
-  for (uint32_t i = 0; i < lobes; ++i) {
+  for (uint32_t i = 0; MAXL > 1 && i < lobes; ++i) {
     const DevLobe& q = m.lobes[i];
     if (i != index && ((p.flags & q.flags) == q.flags)) {
       const bool reflect = dot(n, wi) * dot(n, wo) > 0.0f;

@@ -73,7 +73,7 @@ struct phx_device {
 
   // scene
   DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals;
-  DevBuf<DevMaterial> d_materials; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
+  DevBuf<DevMaterial> d_materials; DevBuf<DevMatLite> d_mat_lite; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
   DevScene scene{};
   uint32_t num_materials = 0;
   uint64_t bvh_nodes = 0, bvh_bytes = 0, num_triangles = 0;
@@ -262,7 +262,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
       const phx_face_set& fs = m.sets[si];
       if (fs.material >= s->num_materials) return fail(PHX_ERR_ARG, "face set material out of range");
       const bool emitter = s->materials[fs.material].is_emitter != 0;
-      DevLight L{(uint32_t)light_tris.size(), 0, 0.0f, fs.material};
+      DevLight L{(uint32_t)light_tris.size(), 0, 0.0f, fs.material, 0.0f, 0.0f, 0.0f, 0.0f};
       for (uint32_t k = 0; k < fs.num_faces; ++k) {
         const uint32_t f = fs.faces[k];
         if (f >= m.num_faces) return fail(PHX_ERR_ARG, "face index out of range");
@@ -284,9 +284,10 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
           prim_normals.insert(prim_normals.end(), nn, nn + 9);
         }
         if (emitter) {  // mesh_t::preprocess -> light_t::make_area (mesh.cpp:108-116), area_light_t (light.cpp:10-45)
-          DevLightTri T{a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], prim, mi | (fs.material << 16), 3 * f};
-          light_tris.push_back(T);
           const v3 ab(b[0] - a[0], b[1] - a[1], b[2] - a[2]), ac(c[0] - a[0], c[1] - a[1], c[2] - a[2]);
+          const v3 gn = normalize_inplace(cross(ab, ac));  // the flat face's normal as k_shade's shading_normal would compute it per sample
+          DevLightTri T{a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], gn.x, gn.y, gn.z, prim, smooth ? 1u : 0u, mi | (fs.material << 16), 3 * f};
+          light_tris.push_back(T);
           L.area += 0.5f * length(cross(ab, ac));  // triangle_t::area, mesh.cpp:293-300; summed in face order (light.cpp:36-39)
           L.num_tris++;
         }
@@ -306,6 +307,14 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   for (uint32_t i = 0; i < s->num_materials; ++i)
     if (bake_material(s->materials[i], L5, mats[i])) return fail(PHX_ERR_ARG, "material with an unknown closure id");
 
+  {  // per light: the pick pdf and the emission of its material, as k_shade evaluated them per sample until round 2
+    const float nlf = (float)lights.size();
+    for (auto& L : lights) {
+      L.lpdf = (1.0f / L.area) / nlf;
+      if (L.material >= s->num_materials) return fail(PHX_ERR_ARG, "light with a material index out of range");
+      L.ex = mats[L.material].ex; L.ey = mats[L.material].ey; L.ez = mats[L.material].ez;
+    }
+  }
   int rc;
   if ((rc = d->d_prim_material.upload(prim_material))) return rc;
   const auto t_bvh0 = std::chrono::steady_clock::now();
@@ -373,6 +382,22 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   }
   sc.diffuse_only = 1;
   for (auto& m : mats) { if (m.per_hit) sc.diffuse_only = 0; for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0; }
+  sc.mat_lite = nullptr;
+  if (sc.diffuse_only) {  // at most one Lambert lobe everywhere (the soups, the Cornell box): a 32-byte material table for k_shade<2>
+    bool single = true;
+    for (auto& m : mats) single = single && m.num_lobes <= 1;
+    if (single) {
+      std::vector<DevMatLite> lite(mats.size());
+      for (size_t i = 0; i < mats.size(); ++i) {
+        const DevMaterial& m = mats[i];
+        lite[i] = DevMatLite{m.lobes[0].wx, m.lobes[0].wy, m.lobes[0].wz, m.num_lobes | (m.lobes[0].flags << 8), m.ex, m.ey, m.ez, 0u};
+        if (m.num_lobes == 0) { lite[i].wx = lite[i].wy = lite[i].wz = 0.0f; lite[i].lobes_flags = 0; }
+      }
+      if ((rc = d->d_mat_lite.upload(lite))) return rc;
+      sc.mat_lite = d->d_mat_lite.p;
+      sc.diffuse_only = 2;
+    }
+  }
   d->num_materials = s->num_materials;
   d->bvh_nodes = bvh_node_count;
   d->bvh_bytes = bvh_elems * sizeof(PoolElem);

@@ -19,8 +19,13 @@
 
 namespace phx {
 
-struct DevLight { uint32_t first_tri, num_tris; float area; uint32_t material; };
-struct DevLightTri { float ax, ay, az, bx, by, bz, cx, cy, cz; uint32_t prim; uint32_t mesh_mat; uint32_t face; };
+// Light table (light_t::make_area, src/light.cpp:10-45).  What k_shade would otherwise fetch through three more dependent loads per
+// shaded hit is resolved once at preprocess, with the same fp32 operations the kernel would use: the pick pdf (1/area)/nlights
+// (spt.hpp:95-149), the light material's emission (material_t::evaluate's e) and, per triangle, the geometric normal of a flat face.
+struct DevLight { uint32_t first_tri, num_tris; float area; uint32_t material; float lpdf, ex, ey, ez; };                 // 32 B
+struct DevLightTri { float ax, ay, az, bx, by, bz, cx, cy, cz, nx, ny, nz; uint32_t prim, smooth, mesh_mat, face; };   // 64 B
+// A material of a scene in which every material is at most ONE Lambert lobe (the soups, the Cornell box): 32 B instead of 544
+struct DevMatLite { float wx, wy, wz; uint32_t lobes_flags /* num_lobes | flags << 8 */; float ex, ey, ez; uint32_t pad; };
 
 struct DevScene {
   const uint32_t* pool;           // the BVH8 pool: 16 words per element, element 0 = root nodelet (bvh8.h)
@@ -29,6 +34,7 @@ struct DevScene {
   const uint32_t* prim_material;  // per primitive (scene_t::triangles() order): material | smooth << 31
   const float* prim_normals;      // 9 floats per primitive (n0,n1,n2) or nullptr when no face is smooth
   const DevMaterial* materials;
+  const DevMatLite* mat_lite;     // diffuse_only == 2: the same table, 32 B per material
   const DevLight* lights;
   const DevLightTri* light_tris;
   uint32_t num_lights;
@@ -40,7 +46,7 @@ struct DevScene {
   uint32_t stack_levels;          // BVH depth
   uint32_t num_elems;             // pool elements (stored breadth first: a prefix of the pool is the top of the tree)
   uint32_t num_cus;               // compute units of the device (persistent grid sizing)
-  uint32_t diffuse_only;          // every lobe of every material is Lambert: k_shade<true>
+  uint32_t diffuse_only;          // 1: every lobe of every material is Lambert (k_shade<1>); 2: and no material has more than one (k_shade<2>)
 };
 
 // counters: [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity)

@@ -441,8 +441,11 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
   return (float)0.212671 * c.x + (float)0.715160 * c.y + (float)0.072169 * c.z;
 }
 
-template <bool DIFFUSE_ONLY, bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
-__global__ void __launch_bounds__(DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(DIFFUSE_ONLY ? 4 : PHX_SHADE_WAVES_G, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+template <int MATS /* DevScene::diffuse_only: 0 any closure, 1 Lambert lobes only, 2 at most one Lambert lobe per material */,
+          bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
+__global__ void __launch_bounds__(MATS ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(MATS ? 4 : PHX_SHADE_WAVES_G, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+  constexpr bool DIFFUSE_ONLY = MATS != 0;
+  constexpr int MAXL = MATS == 2 ? 1 : 8;
   constexpr int PHX_SHADE_BLOCK = DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q];
@@ -511,6 +514,13 @@ __global__ void __launch_bounds__(DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_B
       // material with a hit-dependent weight (glass: Fresnel-driven mix) gets its weights resolved for (n, hits.wi) first.
       const DevMaterial* mp = &sc.materials[pm & 0x7fffffffu];
       DevMaterial mh;
+      if (MATS == 2) {  // the whole material in two 16-byte loads; only the fields named here are ever read (bsdf_f / bsdf_sample <true, 1>)
+        const DevMatLite ml = sc.mat_lite[pm & 0x7fffffffu];
+        mh.num_lobes = ml.lobes_flags & 0xffu; mh.lobes[0].flags = ml.lobes_flags >> 8; mh.lobes[0].type = L_DIFFUSE;
+        mh.lobes[0].wx = ml.wx; mh.lobes[0].wy = ml.wy; mh.lobes[0].wz = ml.wz;
+        mh.ex = ml.ex; mh.ey = ml.ey; mh.ez = ml.ez; mh.sheen_L5 = 0.0f;
+        mp = &mh;
+      }
       if (!DIFFUSE_ONLY && mp->per_hit) { material_at_hit(*mp, n, wo, mh); mp = &mh; }
       const DevMaterial& m = *mp;
       if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
@@ -533,7 +543,7 @@ __global__ void __launch_bounds__(DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_B
         const float bu = 1 - x, bv = lv * x;     // triangle_t::sample, mesh.cpp:318-324
         const v3 la(LT.ax, LT.ay, LT.az), lb(LT.bx, LT.by, LT.bz), lc(LT.cx, LT.cy, LT.cz);
         const v3 P = bu * la + bv * lb + (1 - bu - bv) * lc;
-        const float lpdf = (1.0f / L.area) / nlf;
+        const float lpdf = L.lpdf;  // (1.0f / L.area) / nlf, evaluated at preprocess
         sh_o = v3(p.x + n.x * 0.0001f, p.y + n.y * 0.0001f, p.z + n.z * 0.0001f);
         v3 wl = P - sh_o;
         const float l2 = sdot(wl, wl);
@@ -542,11 +552,10 @@ __global__ void __launch_bounds__(DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_B
         wl = v3(wl.x * oolen, wl.y * oolen, wl.z * oolen);
         if (sdot(n, wl) >= 0.0f) {
           // li(), spt.hpp:212-255 — evaluated before the occlusion test; added by k_trace_shadow if unoccluded
-          const v3 f = bsdf_f<DIFFUSE_ONLY>(m, n, wl, wo);
-          const uint32_t lpm = sc.prim_material[LT.prim];
-          const v3 ln = shading_normal(sc, LT.prim, (lpm >> 31) != 0, lb - la, lc - la, bu, bv);
-          const DevMaterial& lm = sc.materials[L.material];
-          const v3 le(lm.ex, lm.ey, lm.ez);
+          const v3 f = bsdf_f<DIFFUSE_ONLY, MAXL>(m, n, wl, wo);
+          // the light's normal at the sampled point (mesh_t::shading_parameters on the light triangle) and its emission
+          const v3 ln = LT.smooth ? shading_normal(sc, LT.prim, true, lb - la, lc - la, bu, bv) : v3(LT.nx, LT.ny, LT.nz);
+          const v3 le(L.ex, L.ey, L.ez);
           const float pdf = lpdf * dist * dist / fabsf(dot(ln, -wl));
           const v3 li = ((le * 4.0f) * f) * (1.0f / pdf);
           contrib = beta * li;
@@ -570,7 +579,7 @@ __global__ void __launch_bounds__(DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_B
       if (alive) {
         const uint32_t b1 = (depth - 1u) * DIMS_PER_STEP;
         v3 sampled; float pdf; uint32_t fl;
-        const v3 f = bsdf_sample<DIFFUSE_ONLY>(m, n, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, sampled, pdf, fl);
+        const v3 f = bsdf_sample<DIFFUSE_ONLY, MAXL>(m, n, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, sampled, pdf, fl);
         if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) {
           alive = false;
         } else {
@@ -803,12 +812,15 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays) {
   const uint32_t sb = sc.diffuse_only ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
   const dim3 g((capacity + sb - 1) / sb), b(sb);
-  if (sc.diffuse_only) {
-    if (camera_rays) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
-    else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+  if (sc.diffuse_only == 2) {
+    if (camera_rays) hipLaunchKernelGGL((k_shade<2, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade<2, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+  } else if (sc.diffuse_only) {
+    if (camera_rays) hipLaunchKernelGGL((k_shade<1, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade<1, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   } else {
-    if (camera_rays) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
-    else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    if (camera_rays) hipLaunchKernelGGL((k_shade<0, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade<0, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   }
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {

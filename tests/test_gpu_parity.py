@@ -167,6 +167,22 @@ def test_render_all_closures_matches_oracle(xpu, orc):
     assert bits_equal(film[..., :3][fin], ref[..., :3][fin])
 
 
+def test_lambert_only_materials_with_several_lobes_match_oracle(xpu, orc):
+    """k_shade has three material paths: any closure, Lambert lobes only, and at most ONE Lambert lobe per material (a 32-byte
+    material record; the soups and the Cornell box).  This scene has Lambert-only materials with two and three lobes — lobe pick
+    by floor(u * lobes), f summed over lobes, pdf averaged (bsdf.cpp:133-248) — so it runs the middle one."""
+    from phosphorus_mk2_amd import abi, scenes
+    D = abi.LOBE_DIFFUSE
+    mats = [scenes.MaterialDesc([scenes.LobeDesc(D, (0.4, 0.3, 0.2)), scenes.LobeDesc(D, (0.2, 0.3, 0.4))]),
+            scenes.MaterialDesc([scenes.LobeDesc(D, (0.3, 0.1, 0.1)), scenes.LobeDesc(D, (0.1, 0.3, 0.1)), scenes.LobeDesc(D, (0.1, 0.1, 0.3))]),
+            scenes.diffuse(0.73, 0.73, 0.73)]
+    sc = scenes.soup(4000, width=96, height=64, materials=mats)
+    film, st, (ref, ost) = _render_both(xpu, orc, sc, spp=16, seed=9)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"]
+    assert max_pixel_l2(film, ref) < L2_TOL and bits_equal(film[..., :3], ref[..., :3])
+    assert film[..., :3].max() > 0.05
+
+
 def test_glass_per_hit_closures_match_oracle(xpu, orc):
     """Blender's glass node (mix(refraction, glossy, fresnel_dielectric(I.N, backfacing ? 1/IoR : IoR)),
     plugins/blender/blender/shader.hpp:306-335): closure weights evaluated at every hit (bsdf.h: material_at_hit), closures
