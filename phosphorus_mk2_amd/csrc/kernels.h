@@ -49,8 +49,10 @@ struct DevScene {
   uint32_t diffuse_only;          // 1: every lobe of every material is Lambert (k_shade<1>); 2: and no material has more than one (k_shade<2>)
 };
 
-// counters: [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity)
-enum { CNT_SHADOW = 2, CNT_CURSOR = 4, CNT_WORDS = 8 };
+// counters (x CNT_STRIDE words): [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity); [4],[5] chunk cursors
+// every counter on its own 128-byte line: the queue-length counters take one atomic per k_shade workgroup and one address (line)
+// sustains ~90 atomics/us — two counters on one line halve what each gets
+enum { CNT_STRIDE = 32, CNT_SHADOW = 2 * CNT_STRIDE, CNT_CURSOR = 4 * CNT_STRIDE, CNT_WORDS = 6 * CNT_STRIDE };
 struct DevStats {
   unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples;
   // instrumented build only (-DPHX_COUNT=1, `make variant NAME=count`): traversal work, [0] closest-hit rays, [1] shadow rays

@@ -33,7 +33,8 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 // global atomic per workgroup reserves the slots (a returning atomic on one address sustains only
 // ~90 ops/us chip-wide — per-wave atomics made k_shade atomic-bound).  All threads of the block must call.
 #ifndef PHX_SHADE_BLOCK_D
-#define PHX_SHADE_BLOCK_D 512  /* k_shade<DIFFUSE_ONLY>: threads per workgroup */
+#define PHX_SHADE_BLOCK_D 1024  /* Lambert-only k_shade: threads per workgroup.  The kernel is bound by the atomics on the two queue counters (one per
+                                    workgroup and queue): 256 threads 28.3 ms, 512 16.0 ms, 1024 11.3 ms per frame (profiles/README.md) */
 #endif
 #ifndef PHX_SHADE_BLOCK_G
 #define PHX_SHADE_BLOCK_G 512  /* general k_shade (measured on the 16-recipe stand-in: 256: +4 % shade time, 128: +29 %, 64: +144 % — one atomic per workgroup and append) */
@@ -41,20 +42,27 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 #ifndef PHX_SHADE_WAVES_G
 #define PHX_SHADE_WAVES_G 4    /* general k_shade: waves per SIMD the register allocator must leave room for */
 #endif
+// Both queues of a workgroup are appended in ONE round: the wave counts of the two predicates go to LDS, the first lanes of
+// waves 0 and 1 each prefix one of them and issue its atomic — the two round trips to the counters overlap instead of following
+// each other (two barriers and one atomic latency per workgroup instead of four and two).
 template <int SHADE_BLOCK>
-__device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, uint32_t* lds /* [2 * waves + 2] */, int which) {
+__device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, bool want_b, uint32_t* counter_b, uint32_t* lds /* [2 * (waves + 1)] */,
+                                              uint32_t& at_a, uint32_t& at_b) {
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = SHADE_BLOCK >> 6;
-  const unsigned long long mask = __ballot(want);
-  uint32_t* cnt = lds + which * (nwaves + 1);
-  if (lane == 0) cnt[wave] = (uint32_t)__popcll(mask);
+  const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b);
+  uint32_t* cnt_a = lds; uint32_t* cnt_b = lds + nwaves + 1;
+  if (lane == 0) { cnt_a[wave] = (uint32_t)__popcll(mask_a); cnt_b[wave] = (uint32_t)__popcll(mask_b); }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (lane == 0 && wave < 2) {
+    uint32_t* cnt = wave == 0 ? cnt_a : cnt_b;
     uint32_t total = 0;
     for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = cnt[w]; cnt[w] = total; total += c; }
-    cnt[nwaves] = total ? atomicAdd(counter, total) : 0u;
+    cnt[nwaves] = total ? atomicAdd(wave == 0 ? counter_a : counter_b, total) : 0u;
   }
   __syncthreads();
-  return cnt[nwaves] + cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  const unsigned long long below = (1ull << lane) - 1ull;
+  at_a = cnt_a[nwaves] + cnt_a[wave] + (uint32_t)__popcll(mask_a & below);
+  at_b = cnt_b[nwaves] + cnt_b[wave] + (uint32_t)__popcll(mask_b & below);
 }
 
 // ---- camera rays ------------------------------------------------------------------------------------
@@ -86,8 +94,8 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers
 // the first k_shade writes beta, depth and radiance of every path without reading them)
 __global__ void k_begin_pass(PassBuffers pb, uint32_t num_samples) {
   const uint32_t npaths = pb.num_pixels * num_samples;
-  pb.counters[0] = npaths; pb.counters[1] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + 1] = 0;
-  pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + 1] = 0;
+  pb.counters[0] = npaths; pb.counters[CNT_STRIDE] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + CNT_STRIDE] = 0;
+  pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0;
   atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
 }
 
@@ -163,7 +171,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           uint32_t nb = 0;
           if (dfirst & (1u << phase)) { dfirst = PHX_UNI(dfirst & ~(1u << phase)); nb = dq.wave_id * c; }
           else {
-            if (lane == leader) nb = atomicAdd(&dq.cursor[phase], c) + dq.num_waves * c;
+            if (lane == leader) nb = atomicAdd(&dq.cursor[phase * CNT_STRIDE], c) + dq.num_waves * c;
             nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nb, (int)leader));
           }
           if (nb >= qn) {  // this queue is exhausted
@@ -351,11 +359,11 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
   uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
   uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 4);  // PHX_PERM_LUT: 8 octants x 256 masks
-  const uint32_t n_closest = do_closest ? pb.counters[q] : 0u;
-  const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq] : 0u;
+  const uint32_t n_closest = do_closest ? pb.counters[q * CNT_STRIDE] : 0u;
+  const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq * CNT_STRIDE] : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the queues k_shade will append to next: the other ray queue and the other shadow queue
-    if (do_closest) { pb.counters[q ^ 1] = 0; pb.counters[CNT_SHADOW + (sq ^ 1)] = 0; }
+    if (do_closest) { pb.counters[(q ^ 1) * CNT_STRIDE] = 0; pb.counters[CNT_SHADOW + (sq ^ 1) * CNT_STRIDE] = 0; }
     if (n_closest) atomicAdd(&pb.stats->rays_closest, (unsigned long long)n_closest);
     if (n_shadow) atomicAdd(&pb.stats->rays_shadow, (unsigned long long)n_shadow);
   }
@@ -448,9 +456,9 @@ __global__ void __launch_bounds__(MATS ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) 
   constexpr int MAXL = MATS == 2 ? 1 : 8;
   constexpr int PHX_SHADE_BLOCK = DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
-  const uint32_t count = pb.counters[q];
+  const uint32_t count = pb.counters[q * CNT_STRIDE];
   uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
-  if (i == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + 1] = 0; }  // the next k_trace pulls its chunks from here
+  if (i == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0; }  // the next k_trace pulls its chunks from here
   if (blockIdx.x * PHX_SHADE_BLOCK >= count) return;
   if (!DIFFUSE_ONLY) {
     // Bucket the workgroup's 512 hits by material before shading them — what deferred_shading_kernel_t does per
@@ -610,12 +618,12 @@ __global__ void __launch_bounds__(MATS ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) 
     }
   }
   // ---- stream compaction: survivors -> next ray queue, unmasked NEE rays -> shadow queue
-  const uint32_t no = block_append<PHX_SHADE_BLOCK>(alive, &pb.counters[q ^ 1], lds_cnt, 0);
+  uint32_t no, ns;
+  block_append2<PHX_SHADE_BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_cnt, no, ns);
   if (alive) {
     pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
     pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
   }
-  const uint32_t ns = block_append<PHX_SHADE_BLOCK>(want_shadow, &pb.counters[CNT_SHADOW + sq], lds_cnt, 1);
   if (want_shadow) {
     pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
     pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
