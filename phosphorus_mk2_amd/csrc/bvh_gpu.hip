@@ -37,18 +37,20 @@ __host__ __device__ inline float ord2f(uint32_t o) {
 
 struct Box6 { float lo[3], hi[3]; };
 
+// Grid-stride: a wave folds many triangles into its 12 extremes before it touches the 12 shared words — one wave per 64 triangles
+// meant 1.9 M atomics on one cache line for 10 M triangles (21 ms at the ~90 atomics/us one line sustains).
 __global__ void __launch_bounds__(GB) k_prim_bounds(const float* __restrict__ abc, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ cb /* 12 ordered uints: centroid lo/hi, geometry lo/hi */) {
-  const uint32_t i = blockIdx.x * GB + threadIdx.x;
   float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   float glo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, ghi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  if (i < n) {
+  for (uint32_t i = blockIdx.x * GB + threadIdx.x; i < n; i += gridDim.x * GB) {
     const float* t = abc + 9 * (size_t)i;
     Box6 b;
     for (int a = 0; a < 3; ++a) {
       b.lo[a] = fminf(fminf(t[a], t[3 + a]), t[6 + a]);
       b.hi[a] = fmaxf(fmaxf(t[a], t[3 + a]), t[6 + a]);
-      clo[a] = chi[a] = 0.5f * (b.lo[a] + b.hi[a]);
-      glo[a] = b.lo[a]; ghi[a] = b.hi[a];
+      const float c = 0.5f * (b.lo[a] + b.hi[a]);
+      clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
+      glo[a] = fminf(glo[a], b.lo[a]); ghi[a] = fmaxf(ghi[a], b.hi[a]);
     }
     pbox[i] = b;
   }
@@ -243,10 +245,11 @@ __global__ void __launch_bounds__(DP_BLOCK) k_collapse_dp(int n, const uint32_t*
   }
 }
 
+#define BC_STRIDE 32  /* words between the builder's counters: one cache line each */
 // One thread builds one Node8 from BVH2 subtree `qa[e]` into pool element `qb[e]`.
 __global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const float* __restrict__ abc, const uint32_t* __restrict__ prim_material, const uint32_t* __restrict__ qa,
                                                  const uint32_t* __restrict__ qb, uint32_t count, uint32_t* __restrict__ qa_out, uint32_t* __restrict__ qb_out,
-                                                 uint32_t* __restrict__ counters /* [0] pool elements, [1] tris, [2] out queue, [3] nodes */, PoolElem* __restrict__ pool,
+                                                 uint32_t* __restrict__ counters /* x BC_STRIDE words: [0] pool elements, [1] tris, [2] out queue, [3] nodes */, PoolElem* __restrict__ pool,
                                                  const uint32_t* __restrict__ cut, const uint8_t* __restrict__ cut_count) {
   const uint32_t e = blockIdx.x * 64 + threadIdx.x;
   if (e >= count) return;
@@ -324,10 +327,26 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const 
     nd.qlox[s] = ql[0]; nd.qloy[s] = ql[1]; nd.qloz[s] = ql[2]; nd.qhix[s] = qh[0]; nd.qhiy[s] = qh[1]; nd.qhiz[s] = qh[2];
   }
   node_origin_encode(nd, gi[0], gi[1], gi[2], valid);
-  nd.child_base = atomicAdd(&counters[0], n_inner + n_tri);
-  if (n_tri) atomicAdd(&counters[1], n_tri);
-  if (n_inner) atomicAdd(&counters[3], n_inner);
-  const uint32_t qpos = n_inner ? atomicAdd(&counters[2], n_inner) : 0u;
+  // Pool elements and places in the next level's queue are handed out per WAVE: a scan of the lanes' needs (all children | inner
+  // children << 16; a wave needs at most 512 of each) and one atomic per counter, each counter on its own 128-byte line — one
+  // address sustains ~90 atomics per microsecond, and four per node on one line were a quarter of the 10 M-triangle build.  The
+  // lanes beyond `count` have returned; they are the top lanes of the last wave, so every shuffle below reads a live lane.
+  const uint32_t lane = threadIdx.x, own = (n_inner + n_tri) | (n_inner << 16);
+  const int last_lane = (int)__popcll(__ballot(1)) - 1;
+  uint32_t v = own;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, d); if (lane >= (uint32_t)d) v += t; }
+  const uint32_t total = (uint32_t)__shfl((int)v, last_lane);
+  uint32_t base_elems = 0, base_queue = 0;
+  if (lane == 0) {
+    const uint32_t all = total & 0xffffu, inner = total >> 16;
+    base_elems = atomicAdd(&counters[0], all);
+    if (inner) { base_queue = atomicAdd(&counters[2 * BC_STRIDE], inner); atomicAdd(&counters[3 * BC_STRIDE], inner); }
+    if (all - inner) atomicAdd(&counters[1 * BC_STRIDE], all - inner);
+  }
+  base_elems = (uint32_t)__shfl((int)base_elems, 0); base_queue = (uint32_t)__shfl((int)base_queue, 0);
+  nd.child_base = base_elems + ((v - own) & 0xffffu);
+  const uint32_t qpos = base_queue + ((v - own) >> 16);
   // the children's pool elements, in slot order: triangle records now, nodelets by the next level's threads
   uint32_t rank = 0, r = 0;
   for (int s = 0; s < 8; ++s) {
@@ -374,14 +393,14 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   uint32_t* flags = (uint32_t*)dalloc(4 * (size_t)n);
   Box6* nbox = (Box6*)dalloc(sizeof(Box6) * 2 * (size_t)n);
   uint32_t* queues = (uint32_t*)dalloc(4 * 4 * (size_t)n);
-  uint32_t* counters = (uint32_t*)dalloc(64);
+  uint32_t* counters = (uint32_t*)dalloc(4 * BC_STRIDE * sizeof(uint32_t));
   if (!pbox || !cb || !keys || !keys2 || !vals || !sorted || !left || !right || !parent || !first || !last || !flags || !nbox || !queues || !counters) {
     std::snprintf(err, errlen, "hipMalloc failed in the device BVH builder"); cleanup(); return 1;
   }
   const uint32_t init_cb[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   HCHK(hipMemcpyAsync(cb, init_cb, sizeof(init_cb), hipMemcpyHostToDevice, stream));
   const dim3 g((n + GB - 1) / GB), b(GB);
-  hipLaunchKernelGGL(k_prim_bounds, g, b, 0, stream, d_abc, n, pbox, cb);
+  hipLaunchKernelGGL(k_prim_bounds, dim3(std::min<uint32_t>((n + GB - 1) / GB, 2048u)), b, 0, stream, d_abc, n, pbox, cb);
   hipLaunchKernelGGL(k_morton, g, b, 0, stream, pbox, n, cb, keys, vals);
   size_t temp_bytes = 0;
   HCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
@@ -410,7 +429,9 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   HCHK(hipMemcpyAsync(qa[0], &zero_root[0], 4, hipMemcpyHostToDevice, stream));
   HCHK(hipMemcpyAsync(qb[0], &zero_root[1], 4, hipMemcpyHostToDevice, stream));
   uint32_t h_counters[4] = {1u, 0u, 0u, 1u};  // element 0 is the root nodelet
-  HCHK(hipMemcpyAsync(counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
+  uint32_t h_lines[4 * BC_STRIDE] = {0};
+  for (int k = 0; k < 4; ++k) h_lines[k * BC_STRIDE] = h_counters[k];
+  HCHK(hipMemcpyAsync(counters, h_lines, sizeof(h_lines), hipMemcpyHostToDevice, stream));
   Tree2 T{left, right, first, last, nbox, sorted, (int)n};
   // optimal collapse (PHX_LBVH_COLLAPSE=0: the greedy surface-area expansion)
   uint32_t* cut = nullptr; uint8_t* cut_count = nullptr; float* sub = nullptr;
@@ -428,11 +449,12 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
     ++depth;
     hipLaunchKernelGGL(k_collapse, dim3((count + 63) / 64), dim3(64), 0, stream, T, grid, d_abc, d_prim_material, qa[cur], qb[cur], count, qa[cur ^ 1], qb[cur ^ 1],
                        counters, pool, cut, cut_count);
-    HCHK(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+    HCHK(hipMemcpyAsync(h_lines, counters, sizeof(h_lines), hipMemcpyDeviceToHost, stream));
     HCHK(hipStreamSynchronize(stream));
+    for (int k = 0; k < 4; ++k) h_counters[k] = h_lines[k * BC_STRIDE];
     count = h_counters[2];
     const uint32_t z = 0;
-    HCHK(hipMemcpyAsync(counters + 2, &z, 4, hipMemcpyHostToDevice, stream));
+    HCHK(hipMemcpyAsync(counters + 2 * BC_STRIDE, &z, 4, hipMemcpyHostToDevice, stream));
     cur ^= 1;
     if (count > 0 && depth >= PHX_MAX_BVH_DEPTH) {
       std::snprintf(err, errlen, "tree too deep: more than %d levels (PHX_MAX_BVH_DEPTH, the traversal stack in LDS)", PHX_MAX_BVH_DEPTH);
