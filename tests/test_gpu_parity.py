@@ -544,6 +544,16 @@ def test_random_scenes_match_oracle(xpu, orc, seed):
     assert bits_equal(film[..., 4:7], nrm)
 
 
+def test_differential_fuzz_of_sixty_random_scenes(xpu):
+    """scripts/fuzz_parity.py (3 000 scenes in profiles/r02_fuzz_parity_3000.json) on sixty fresh seeds: random scenes x random
+    options, ray counts + film + normals bit for bit against the oracle under the device's tie rule"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "60", "70000"], capture_output=True, text=True, timeout=600)
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0 and out["failed"] == 0 and out["scenes"] == 60, (out, p.stderr[-2000:])
+
+
 def test_instrumented_build_counts_the_same_frame(xpu, tmp_path):
     """libphx_hip_count.so (the same sources with -DPHX_COUNT=1: bench.py's roofline reads node visits and triangle tests from it)
     must render the very same film, and its counters must add up: every ray visits the root, every wave iteration runs a block."""
