@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the device against the CPU oracle: N scenes nobody designed (tests/test_gpu_parity.py::_random_scene:
 shared vertices, smooth / flat faces, closure zoo + glass, one or two lights, optional environment, rotated camera, ragged
-film) x random options (spp, depth, builder, samples in flight, tiles per batch, callback tiles, seed).  Ray counts, film and
+film; every fourth scene a soup or showroom of 64..60 000 triangles with random closure recipes: deep trees) x random options (spp, depth, builder, samples in flight, tiles per batch, callback tiles, seed).  Ray counts, film and
 normals channel must agree bit for bit.  python scripts/fuzz_parity.py [N] [first_seed]  ->  one JSON line"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,15 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 bad, ties, rays, t0 = [], [], 0, time.time()
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed ^ 0x5bd1e995)
-    sc = _random_scene(seed)
+    if seed % 4 == 3:  # every fourth scene is a deep tree: a soup or the showroom with 64..60 000 triangles and random closure recipes
+        from phosphorus_mk2_amd import scenes
+        ntri = int(64 * (60000 / 64) ** rng.random())
+        zoo = scenes.closure_zoo() + [scenes.glass(float(rng.uniform(1.2, 1.8)), float(rng.choice([0.0, 0.15])))]
+        mats = [zoo[int(k)] for k in rng.choice(len(zoo), int(rng.integers(1, 6)), replace=False)]
+        W, H = int(rng.integers(3, 17)) * 8, int(rng.integers(20, 97))
+        sc = scenes.soup(ntri, seed=seed, width=W, height=H, materials=mats) if rng.random() < 0.6 else scenes.showroom(ntri, seed=seed, width=W, height=H, materials=mats)
+    else:
+        sc = _random_scene(seed)
     spp = int(rng.choice([1, 2, 3, 4, 7, 9, 16, 25])); depth = int(rng.choice([1, 2, 3, 5, 9, 12]))
     kw = dict(bvh_builder=str(rng.choice(["host", "device", "auto"])), samples_in_flight=int(rng.choice([0, 1, 3])),
               tiles_per_batch=int(rng.choice([0, 1, 2, 5])), callback_tiles=bool(rng.random() < 0.3), native_sink=bool(rng.random() < 0.5))
