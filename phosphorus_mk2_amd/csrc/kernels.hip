@@ -129,6 +129,9 @@ struct LdsStack {
 #ifndef PHX_PROBE_VMEM
 #define PHX_PROBE_VMEM 0
 #endif
+#ifndef PHX_PROBE_VMEM_DWORD
+#define PHX_PROBE_VMEM_DWORD 0
+#endif
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
 struct DynQueue {            // DYN: the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
@@ -259,7 +262,13 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         if (!in_lds) {
           const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)(ni ^ 1u) * 4u;
 #pragma unroll
-          for (int k = 0; k < PHX_PROBE_VMEM; ++k) { const uint4 v = s4[k]; w[2] ^= (v.x ^ v.y ^ v.z ^ v.w) & (refill_min >> 31); }
+          for (int k = 0; k < PHX_PROBE_VMEM; ++k) {
+#if PHX_PROBE_VMEM_DWORD
+            w[2] ^= s4[k].x & (refill_min >> 31);   // same addresses, a quarter of the bytes
+#else
+            const uint4 v = s4[k]; w[2] ^= (v.x ^ v.y ^ v.z ^ v.w) & (refill_min >> 31);
+#endif
+          }
         }
 #endif
 #if PHX_PERM_LUT
