@@ -352,9 +352,10 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 // Trace kernel: closest-hit rays of ray queue `q` (if do_closest) and any-hit rays of the shadow queue `sq`
 // filled by the previous k_shade (if do_shadow) in ONE launch, so that late bounces with few rays still fill
 // the chip.  Queue lengths are only known on the device.
-//   DYN (default): the launch is persistent — exactly the resident workgroups — and every WAVE pulls chunks of <= 256 rays
-//   from two global cursors: its first chunk is its own by position (no atomic), later ones cost one returning atomic per
-//   256 rays (~45/us at the baseline frame, under the ~90/us one address sustains; 64-ray chunks are atomic-bound).  A wave
+//   DYN (default): the launch is persistent — exactly the resident workgroups — and every WAVE pulls chunks of <= 512 rays
+//   from two global cursors (each on its own cache line): its first chunk is its own by position (no atomic), later ones cost
+//   one returning atomic per chunk, which the wave waits for (~17/us at the baseline frame; one address sustains ~90/us, and
+//   64-ray chunks are atomic-bound).  A wave
 //   drains once per launch, not once per slice, and a slow image region is shared by everyone: -6 % trace time.
 //   !DYN: the grid is a fixed multiple of the resident workgroups and every workgroup owns one contiguous range of each
 //   queue, refilled through an LDS cursor.  The split is XCD-aware: workgroups b, b+8, ... share an XCD and its L2, so
@@ -733,13 +734,14 @@ const TraceEnv& trace_env() {
     auto geti = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     TraceEnv t;
     t.gmul = geti("PHX_TRACE_GRID", 4); t.gmul0 = geti("PHX_TRACE_GRID0", 16); t.inter0 = geti("PHX_TRACE_INTER0", 1);
-    t.refill = (uint32_t)geti("PHX_REFILL", 8); t.dyn = geti("PHX_TRACE_DYN", 1); t.dyn_grid = geti("PHX_TRACE_DYN_GRID", 1);
+    t.refill = (uint32_t)geti("PHX_REFILL", 12); t.dyn = geti("PHX_TRACE_DYN", 1); t.dyn_grid = geti("PHX_TRACE_DYN_GRID", 1);
     // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
     t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
     t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
     t.wg_cap = geti("PHX_TRACE_WG_CAP", 0);  // experiment: at most this many k_trace workgroups per CU (leaves wave slots to another stream)
-    // static split: slices of >= 32 chunks; dynamic: chunks of <= 4 x 64 rays (64-ray chunks are atomic-bound, 512+ leave tails)
-    t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : 4);
+    // static split: slices of >= 32 chunks; dynamic: chunks of <= 8 x 64 rays (k_trace ms per frame at 100 k by chunk size: 128 rays
+    // 75.7, 256 66.7, 384 64.4, 512 63.7, 768 63.9, 1024 64.2: a wave waits for its cursor atomic; profiles/r02_n_knob_sweep.log)
+    t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : 8);
     return t;
   }();
   return e;
