@@ -47,6 +47,8 @@ for seed in range(first, first + n):
         rays += st["rays_closest"] + st["rays_shadow"]
     except Exception as e:  # a device error is a finding too
         why = [f"exception: {e}"]
+    if (seed - first) % 250 == 249:  # a long run must keep writing (the GPU pool kills silent commands)
+        print(f"{seed - first + 1} scenes, {len(bad)} failed, {rays} rays, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     if why:
         bad.append({"seed": seed, "spp": spp, "depth": depth, "options": kw, "film_seed": fseed, "differs": why})
 print(json.dumps({"scenes": n, "first_seed": first, "failed": len(bad), "failures": bad[:20], "scenes_where_the_reference_tie_rule_differs": ties, "rays_compared": rays, "seconds": time.time() - t0}))
