@@ -383,6 +383,8 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   sc.diffuse_only = 1;
   for (auto& m : mats) { if (m.per_hit) sc.diffuse_only = 0; for (uint32_t k = 0; k < m.num_lobes; ++k) if (m.lobes[k].type != L_DIFFUSE) sc.diffuse_only = 0; }
   sc.mat_lite = nullptr;
+  sc.any_per_hit = 0;
+  for (auto& m : mats) if (m.per_hit) sc.any_per_hit = 1;
   if (sc.diffuse_only) {  // at most one Lambert lobe everywhere (the soups, the Cornell box): a 32-byte material table for k_shade<2>
     bool single = true;
     for (auto& m : mats) single = single && m.num_lobes <= 1;

@@ -47,6 +47,7 @@ struct DevScene {
   uint32_t num_elems;             // pool elements (stored breadth first: a prefix of the pool is the top of the tree)
   uint32_t num_cus;               // compute units of the device (persistent grid sizing)
   uint32_t diffuse_only;          // 1: every lobe of every material is Lambert (k_shade<1>); 2: and no material has more than one (k_shade<2>)
+  uint32_t any_per_hit;           // some material's closure weights depend on the hit (glass): k_shade<0>; none: k_shade<3>
 };
 
 // counters (x CNT_STRIDE words): [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity); [4],[5] chunk cursors

@@ -459,10 +459,12 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
   return (float)0.212671 * c.x + (float)0.715160 * c.y + (float)0.072169 * c.z;
 }
 
-template <int MATS /* DevScene::diffuse_only: 0 any closure, 1 Lambert lobes only, 2 at most one Lambert lobe per material */,
+template <int MATS /* 0 any closure; 3 any closure, none with hit-dependent weights (every material read stays a global load: with the
+                      per-hit copy in scratch the material pointer is of either address space and every read a flat load);
+                      1 Lambert lobes only; 2 at most one Lambert lobe per material (DevScene::diffuse_only, any_per_hit) */,
           bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
-__global__ void __launch_bounds__(MATS ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(MATS ? 4 : PHX_SHADE_WAVES_G, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
-  constexpr bool DIFFUSE_ONLY = MATS != 0;
+__global__ void __launch_bounds__((MATS == 1 || MATS == 2) ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu((MATS == 1 || MATS == 2) ? 4 : PHX_SHADE_WAVES_G, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+  constexpr bool DIFFUSE_ONLY = MATS == 1 || MATS == 2;
   constexpr int MAXL = MATS == 2 ? 1 : 8;
   constexpr int PHX_SHADE_BLOCK = DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(MATS ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) 
         mh.ex = ml.ex; mh.ey = ml.ey; mh.ez = ml.ez; mh.sheen_L5 = 0.0f;
         mp = &mh;
       }
-      if (!DIFFUSE_ONLY && mp->per_hit) { material_at_hit(*mp, n, wo, mh); mp = &mh; }
+      if (MATS == 0 && mp->per_hit) { material_at_hit(*mp, n, wo, mh); mp = &mh; }
       const DevMaterial& m = *mp;
       if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
       const v3 e(m.ex, m.ey, m.ez);
@@ -837,9 +839,12 @@ void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   } else if (sc.diffuse_only) {
     if (camera_rays) hipLaunchKernelGGL((k_shade<1, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
     else hipLaunchKernelGGL((k_shade<1, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
-  } else {
+  } else if (sc.any_per_hit) {
     if (camera_rays) hipLaunchKernelGGL((k_shade<0, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
     else hipLaunchKernelGGL((k_shade<0, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+  } else {
+    if (camera_rays) hipLaunchKernelGGL((k_shade<3, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade<3, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   }
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
