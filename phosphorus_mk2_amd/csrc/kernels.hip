@@ -123,6 +123,17 @@ struct LdsStack {
 #define PHX_STEPS_PER_REFILL 1
 #endif
 // Sensitivity probes (profiles/README.md), never in the product build: extra FMAs / extra 16-byte loads per node visit.
+// PHX_WG_CURSOR: the chunks of the persistent launch are handed out in two levels.  A WORKGROUP takes 16 chunks' worth of
+// consecutive rays from the global cursor at a time; its waves take their chunks from that range through a 64-bit word in LDS
+// (next | end << 32: one ds_add returns a consistent pair).  The wave that finds the range used up fetches the next one
+// (try-lock in LDS, re-check under the lock); waves that lose the race go on traversing and ask again at their next refill.
+// Sixteen waves of one CU then work on neighbouring pixels, and the global cursor takes 1/16 of the atomics.
+#ifndef PHX_WG_CURSOR
+#define PHX_WG_CURSOR 1
+#endif
+#ifndef PHX_WG_CHUNKS
+#define PHX_WG_CHUNKS 16u  /* chunks in a workgroup's range (fewer when the queue is too short to give every workgroup four ranges) */
+#endif
 #ifndef PHX_PROBE_VALU
 #define PHX_PROBE_VALU 0
 #endif
@@ -135,6 +146,7 @@ struct LdsStack {
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
 struct DynQueue {            // DYN: the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
+  uint32_t r0, r1;           // PHX_WG_CURSOR: rays in a workgroup's range
   uint32_t wave_id, num_waves;
   uint32_t* cursor;          // pb.counters + CNT_CURSOR: two global cursors, zeroed by the kernel that filled the queues
 };
@@ -152,7 +164,10 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
-  uint32_t dlo = 0, dhi = 0, dfirst = 3u;  // DYN: the wave's current chunk [dlo, dhi) and "first chunk not yet taken" bits
+  uint32_t dlo = 0, dhi = 0;  // DYN: the wave's current chunk [dlo, dhi)
+#if !PHX_WG_CURSOR
+  uint32_t dfirst = 3u;       // "first chunk not yet taken" bits
+#endif
 #if PHX_COUNT
   uint32_t cnt_lds[2] = {0, 0}, cnt_mem[2] = {0, 0}, cnt_tri[2] = {0, 0};  // instrumented build: this lane's traversal work
   uint32_t cnt_iter = 0, cnt_nb = 0, cnt_tb = 0, cnt_refill = 0;              // ... and the wave's (wave-uniform)
@@ -171,6 +186,43 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       if (DYN) {
         if (dlo >= dhi) {  // chunk used up: the first one is the wave's by position, later ones come from the global cursor
           const uint32_t c = phase == 0u ? dq.c0 : dq.c1, qn = phase == 0u ? dq.n0 : dq.n1;
+#if PHX_WG_CURSOR
+          uint32_t got_lo = 0, got_hi = 0, st = 1;  // st: 0 a chunk, 1 ask again later, 2 this queue is exhausted
+          if (lane == leader) {
+            unsigned long long* pack = reinterpret_cast<unsigned long long*>(cursor) + phase;
+            uint32_t* fetching = cursor + 4 + phase; uint32_t* done = cursor + 6 + phase;
+            const unsigned long long old = __hip_atomic_fetch_add(pack, (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t s0 = (uint32_t)old, e0 = (uint32_t)(old >> 32);
+            if (s0 < e0) { got_lo = s0; got_hi = min(s0 + c, e0); st = 0; }
+            else if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) st = 2;
+            else if (atomicCAS(fetching, 0u, 1u) == 0u) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              const unsigned long long cur = __hip_atomic_load(pack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if ((uint32_t)cur < (uint32_t)(cur >> 32)) st = 1;  // another wave refilled the range in the meantime
+              else if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) st = 2;
+              else {
+                const uint32_t cwg = phase == 0u ? dq.r0 : dq.r1;
+                const uint32_t nb = atomicAdd(&dq.cursor[phase * CNT_STRIDE], cwg) + gridDim.x * cwg;
+                if (nb >= qn) { __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); st = 2; }
+                else {
+                  const uint32_t end = min(nb + cwg, qn);
+                  got_lo = nb; got_hi = min(nb + c, end); st = 0;  // the fetching wave keeps the range's first chunk
+                  __hip_atomic_store(pack, (unsigned long long)(nb + c) | ((unsigned long long)end << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __hip_atomic_store(fetching, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          st = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)st, (int)leader));
+          if (st == 2u) {  // this queue is exhausted
+            phase = PHX_UNI(phase + 1u);
+            if (phase < 2u || __ballot(active) != 0ull) { if (phase < 2u) continue; } else break;
+          } else if (st == 0u) {
+            dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)got_lo, (int)leader));
+            dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)got_hi, (int)leader));
+          } else if (__ballot(active) == 0ull) { __builtin_amdgcn_s_sleep(4); continue; }  // nothing to do but wait for the fetching wave
+#else
           uint32_t nb = 0;
           if (dfirst & (1u << phase)) { dfirst = PHX_UNI(dfirst & ~(1u << phase)); nb = dq.wave_id * c; }
           else {
@@ -181,6 +233,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             phase = PHX_UNI(phase + 1u);
             if (phase < 2u || __ballot(active) != 0ull) { if (phase < 2u) continue; } else break;
           } else { dlo = PHX_UNI(nb); dhi = PHX_UNI(min(nb + c, qn)); }
+#endif
         }
         if (phase >= 2u) { hi = 0; base = 0; }
         else {
@@ -352,10 +405,11 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 // Trace kernel: closest-hit rays of ray queue `q` (if do_closest) and any-hit rays of the shadow queue `sq`
 // filled by the previous k_shade (if do_shadow) in ONE launch, so that late bounces with few rays still fill
 // the chip.  Queue lengths are only known on the device.
-//   DYN (default): the launch is persistent — exactly the resident workgroups — and every WAVE pulls chunks of <= 512 rays
-//   from two global cursors (each on its own cache line): its first chunk is its own by position (no atomic), later ones cost
-//   one returning atomic per chunk, which the wave waits for (~17/us at the baseline frame; one address sustains ~90/us, and
-//   64-ray chunks are atomic-bound).  A wave
+//   DYN (default): the launch is persistent — exactly the resident workgroups — and work is handed out in two levels
+//   (PHX_WG_CURSOR): a workgroup takes a range of 16 x 64 consecutive rays from a global cursor (its first range is its own by
+//   position), its waves take 64-ray chunks out of that range through a word in LDS.  Fine chunks keep the drain phase short,
+//   and the global cursor sees one returning atomic per 1024 rays instead of one per chunk (which the wave has to wait for:
+//   with per-wave global chunks 512 rays were the optimum, 64-ray chunks were atomic-bound).  A wave
 //   drains once per launch, not once per slice, and a slow image region is shared by everyone: -6 % trace time.
 //   !DYN: the grid is a fixed multiple of the resident workgroups and every workgroup owns one contiguous range of each
 //   queue, refilled through an LDS cursor.  The split is XCD-aware: workgroups b, b+8, ... share an XCD and its L2, so
@@ -368,7 +422,7 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
   uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
-  uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 4);  // PHX_PERM_LUT: 8 octants x 256 masks
+  uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 8);  // PHX_PERM_LUT: 8 octants x 256 masks
   const uint32_t n_closest = do_closest ? pb.counters[q * CNT_STRIDE] : 0u;
   const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq * CNT_STRIDE] : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -413,6 +467,20 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
     // ~min_chunks chunks per wave for mid-size queues, 64 .. target_chunks*64 rays each
     auto chunk_of = [&](uint32_t n) { return min(max((n / (dq.num_waves * max(min_chunks, 1u)) + 63u) & ~63u, 64u), target_chunks * 64u); };
     dq.c0 = chunk_of(n_shadow); dq.c1 = chunk_of(n_closest);
+    // a workgroup's range: PHX_WG_CHUNKS chunks, fewer when the queue could not give every workgroup four such ranges
+    auto range_of = [&](uint32_t n, uint32_t c) { return c * min(max(n / (gridDim.x * c * 4u), 1u), PHX_WG_CHUNKS); };
+    dq.r0 = range_of(n_shadow, dq.c0); dq.r1 = range_of(n_closest, dq.c1);
+#if PHX_WG_CURSOR
+    if (threadIdx.x == 0) {  // the workgroup's first range is its own by position; read by the waves after the barrier below
+      unsigned long long* pack = reinterpret_cast<unsigned long long*>(cursor);
+      for (uint32_t p = 0; p < 2u; ++p) {
+        const uint32_t cwg = p == 0u ? dq.r0 : dq.r1, qn = p == 0u ? n_shadow : n_closest;
+        const uint32_t lo = min(blockIdx.x * cwg, qn), hi = min(lo + cwg, qn);
+        pack[p] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        cursor[4 + p] = 0u; cursor[6 + p] = 0u;
+      }
+    }
+#endif
   } else {
     range(n_shadow, slo, shi);
     range(n_closest, clo, chi);
@@ -422,7 +490,7 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
   // keeps an 80-byte stride in LDS (PHX_NODE_LDS_BYTES, bvh8.h)
   const uint4* g4 = reinterpret_cast<const uint4*>(sc.pool);
   for (uint32_t i = threadIdx.x; i < ntop * 4u; i += BLOCK) top[(i >> 2) * (PHX_NODE_LDS_BYTES / 16u) + (i & 3u)] = g4[i];
-  if (threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
+  if (!DYN && threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
 #if PHX_PERM_LUT
   for (uint32_t i = threadIdx.x; i < 2048u; i += BLOCK) perm_lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
 #endif
@@ -741,9 +809,10 @@ const TraceEnv& trace_env() {
     t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
     t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
     t.wg_cap = geti("PHX_TRACE_WG_CAP", 0);  // experiment: at most this many k_trace workgroups per CU (leaves wave slots to another stream)
-    // static split: slices of >= 32 chunks; dynamic: chunks of <= 8 x 64 rays (k_trace ms per frame at 100 k by chunk size: 128 rays
-    // 75.7, 256 66.7, 384 64.4, 512 63.7, 768 63.9, 1024 64.2: a wave waits for its cursor atomic; profiles/r02_n_knob_sweep.log)
-    t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : 8);
+    // static split: slices of >= 32 chunks; dynamic: 64-ray chunks out of a workgroup's range of 16 (PHX_WG_CURSOR; k_trace ms per
+    // frame at 100 k: 60.8 — with one global atomic per WAVE and chunk the best was 63.7 at 512 rays: 128 rays 75.7, 256 66.7,
+    // 384 64.4, 768 63.9, 1024 64.2; profiles/r02_n_knob_sweep.log, r02_o_wg_cursor.log)
+    t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : (PHX_WG_CURSOR ? 1 : 8));
     return t;
   }();
   return e;
@@ -783,11 +852,11 @@ TracePlan trace_plan(const DevScene& sc) {
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
     uint32_t ntop_req = E.ntop_env;
     if (!ntop_req) {
-      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.levels * blk * 8u + 16u + (PHX_PERM_LUT ? 2048u : 0u);
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
       ntop_req = share > stacks + 9u * PHX_NODE_LDS_BYTES ? (share - stacks) / PHX_NODE_LDS_BYTES : 9u;
     }
     ntop_out = std::min(ntop_req, sc.num_elems);
-    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.levels * blk * 8u + 16u + (PHX_PERM_LUT ? 2048u : 0u);
+    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
     return std::min(160u * 1024u / lds_out, 2048u / blk);
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
