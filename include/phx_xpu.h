@@ -200,7 +200,7 @@ typedef struct phx_stats {
   /* the k_trace launch plan of the preprocessed scene (kernels.hip: trace_plan) */
   uint64_t trace_block;      /* threads per k_trace workgroup: 256, 512 or 1024 */
   uint64_t trace_ntop;       /* top-of-tree elements staged in LDS by every workgroup */
-  uint64_t trace_levels;     /* per-lane stack entries in LDS (= tree depth - 1, at least 2) */
+  uint64_t trace_levels;     /* per-lane stack entries (= tree depth - 1, at least 2) */
   uint64_t trace_waves_per_cu; /* resident k_trace waves per compute unit with that LDS footprint */
   uint64_t bvh_depth;        /* levels of the 8-wide tree (<= 64) */
   uint64_t paths_in_flight;  /* paths carried per wavefront pass in the last frame (pixels of a batch x samples) */
@@ -218,6 +218,7 @@ typedef struct phx_stats {
   uint64_t tri_pending_lane_iters; /* instrumented: lanes that sit out the node block because triangles of their last node are pending */
   uint64_t stack_pushes[8];    /* instrumented: pushes onto the per-lane stack of pending sibling groups, by the depth they land at (7 = 7 and deeper) */
   double   bvh_cost_model;     /* modelled traversal cost of the tree in use (the optimal collapse's objective; area units) */
+  uint64_t trace_lds_levels;   /* ... of which this many live in LDS (deep trees: the rest spills to HBM) */
   uint64_t bvh_built_on_device; /* 1: the tree in use was built on the device */
 } phx_stats;
 

@@ -72,7 +72,7 @@ struct phx_device {
   bool preprocessed = false;
 
   // scene
-  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals;
+  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals; DevBuf<uint2> d_spill;
   DevBuf<DevMaterial> d_materials; DevBuf<DevMatLite> d_mat_lite; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
   DevScene scene{};
   uint32_t num_materials = 0;
@@ -406,7 +406,12 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   d->bvh_build_ms = std::chrono::duration<double, std::milli>(t_bvh1 - t_bvh0).count();
   d->preprocess_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pre0).count();
   d->num_triangles = prim_material.size();
+  sc.stack_spill = nullptr; sc.spill_stride = 0;
   d->plan = trace_plan(sc);
+  if (d->plan.spill_threads) {  // stack levels below the ones k_trace keeps in LDS (kernels.hip: trace_plan)
+    if ((rc = d->d_spill.alloc((size_t)d->plan.spill_threads * (d->plan.levels - d->plan.lds_levels)))) return rc;
+    sc.stack_spill = d->d_spill.p; sc.spill_stride = d->plan.spill_threads;
+  }
   d->preprocessed = true;
   return PHX_OK;
 }
@@ -446,7 +451,7 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   *out = d->stats;
   out->bvh_nodes = d->bvh_nodes; out->bvh_bytes = d->bvh_bytes; out->triangles = d->num_triangles;
   out->preprocess_ms = d->preprocess_ms; out->bvh_build_ms = d->bvh_build_ms;
-  out->trace_block = d->plan.block; out->trace_ntop = d->plan.ntop; out->trace_levels = d->plan.levels;
+  out->trace_block = d->plan.block; out->trace_ntop = d->plan.ntop; out->trace_levels = d->plan.levels; out->trace_lds_levels = d->plan.lds_levels;
   out->trace_waves_per_cu = (uint64_t)d->plan.wg_per_cu * (d->plan.block / 64u); out->bvh_depth = d->scene.stack_levels;
   out->paths_in_flight = d->paths_in_flight;
   out->bvh_cost_model = d->bvh_cost_model; out->bvh_built_on_device = d->bvh_built_on_device;

@@ -48,6 +48,8 @@ struct DevScene {
   uint32_t num_cus;               // compute units of the device (persistent grid sizing)
   uint32_t diffuse_only;          // 1: every lobe of every material is Lambert (k_shade<1>); 2: and no material has more than one (k_shade<2>)
   uint32_t any_per_hit;           // some material's closure weights depend on the hit (glass): k_shade<0>; none: k_shade<3>
+  uint2* stack_spill;             // k_trace<.,.,.,SPILL>: stack entries below the levels kept in LDS, [level - lds_levels][thread of the grid]
+  uint32_t spill_stride;          // threads of the largest k_trace grid (0 = every level is in LDS)
 };
 
 // counters (x CNT_STRIDE words): [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity); [4],[5] chunk cursors
@@ -83,7 +85,7 @@ struct PassBuffers {
 };
 
 // shape of a k_trace launch on a scene (reported through phx_stats so that tests can assert which plan a tree ran with)
-struct TracePlan { uint32_t block, ntop, levels, lds_bytes, wg_per_cu; };
+struct TracePlan { uint32_t block, ntop, levels, lds_bytes, wg_per_cu, lds_levels, spill_threads; };
 TracePlan trace_plan(const DevScene& sc);
 // per device, once: lets the traversal kernels use the CU's full 160 KB of LDS as dynamic shared memory
 hipError_t init_kernels_on_current_device();

@@ -134,6 +134,12 @@ struct LdsStack {
 #ifndef PHX_WG_CHUNKS
 #define PHX_WG_CHUNKS 16u  /* chunks in a workgroup's range (fewer when the queue is too short to give every workgroup four ranges) */
 #endif
+#ifndef PHX_SPILL_FROM_LEVELS
+#define PHX_SPILL_FROM_LEVELS 10u  /* trees with this many stack levels or more keep only PHX_SPILL_LDS_LEVELS of them in LDS */
+#endif
+#ifndef PHX_SPILL_LDS_LEVELS
+#define PHX_SPILL_LDS_LEVELS 7u
+#endif
 #ifndef PHX_PROBE_VALU
 #define PHX_PROBE_VALU 0
 #endif
@@ -150,9 +156,10 @@ struct DynQueue {            // DYN: the launch is persistent and every WAVE pul
   uint32_t wave_id, num_waves;
   uint32_t* cursor;          // pb.counters + CNT_CURSOR: two global cursors, zeroed by the kernel that filled the queues
 };
-template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */, bool DYN>
+template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */, bool DYN, bool SPILL /* the stack's deep levels live in HBM */>
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
-                                             uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t refill_min,
+                                             uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t lds_levels,
+                                             uint2* spill_base /* this thread's column of sc.stack_spill */, uint32_t refill_min,
                                              const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0,
                                              const DynQueue dq, const uint8_t* __restrict__ perm_lut) {
   const uint32_t lane = __lane_id();
@@ -288,7 +295,10 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #if PHX_COUNT
           ++cnt_push[sp < 7 ? sp : 7];
 #endif
-          stack_base[sp * BLOCK] = make_uint2(ng_base, rest); ++sp;
+          // SPILL: the top lds_levels entries of the stack live in LDS, the rare deeper ones in HBM (sc.stack_spill)
+          if (!SPILL || (uint32_t)sp < lds_levels) stack_base[sp * BLOCK] = make_uint2(ng_base, rest);
+          else spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride] = make_uint2(ng_base, rest);
+          ++sp;
         }
         const uint32_t slot = (bit - 24u) ^ r.oct_inv;
         const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
@@ -378,7 +388,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           active = false;
         } else {
           --sp;
-          const uint2 e = stack_base[sp * BLOCK];
+          uint2 e;
+          if (!SPILL || (uint32_t)sp < lds_levels) e = stack_base[sp * BLOCK];
+          else e = spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride];
           ng_base = e.x; ng_hits = e.y;
         }
       }
@@ -415,7 +427,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 //   queue, refilled through an LDS cursor.  The split is XCD-aware: workgroups b, b+8, ... share an XCD and its L2, so
 //   each XCD gets a contiguous eighth of the queue.
 // Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
-template <int BLOCK, bool GEN, bool DYN>
+template <int BLOCK, bool GEN, bool DYN, bool SPILL = false>
 __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
                                                  int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t gmul, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
@@ -495,7 +507,8 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
   for (uint32_t i = threadIdx.x; i < 2048u; i += BLOCK) perm_lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
 #endif
   __syncthreads();
-  trace_stream<BLOCK, GEN, DYN>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, refill_min, top, ntop, sample0, dq, perm_lut);
+  trace_stream<BLOCK, GEN, DYN, SPILL>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
+                                       refill_min, top, ntop, sample0, dq, perm_lut);
 }
 
 // stage-level hook (phx_dev_trace): one ray per lane run to completion with the plain traverse8 loop of bvh8.h.  The per-lane
@@ -797,7 +810,7 @@ void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_s
 namespace {
 struct TraceEnv {
   int gmul, gmul0, inter0, dyn, dyn_grid, wg_cap;
-  uint32_t refill, block_env, ntop_env, min_chunks, target_chunks;
+  uint32_t refill, block_env, ntop_env, min_chunks, target_chunks, lds_levels_env;
 };
 const TraceEnv& trace_env() {
   static const TraceEnv e = [] {
@@ -808,6 +821,7 @@ const TraceEnv& trace_env() {
     // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
     t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
     t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
+    t.lds_levels_env = (uint32_t)geti("PHX_LDS_LEVELS", 0);  // stack levels kept in LDS (0 = chosen by trace_plan)
     t.wg_cap = geti("PHX_TRACE_WG_CAP", 0);  // experiment: at most this many k_trace workgroups per CU (leaves wave slots to another stream)
     // static split: slices of >= 32 chunks; dynamic: 64-ray chunks out of a workgroup's range of 16 (PHX_WG_CURSOR; k_trace ms per
     // frame at 100 k: 60.8 — with one global atomic per WAVE and chunk the best was 63.7 at 512 rays: 128 rays 75.7, 256 66.7,
@@ -823,6 +837,7 @@ void for_each_trace_kernel(F&& f) {
   f(reinterpret_cast<const void*>(&k_trace<256, false, true>)); f(reinterpret_cast<const void*>(&k_trace<512, false, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true>));
   f(reinterpret_cast<const void*>(&k_trace<256, true, false>)); f(reinterpret_cast<const void*>(&k_trace<512, true, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, true, false>));
   f(reinterpret_cast<const void*>(&k_trace<256, false, false>)); f(reinterpret_cast<const void*>(&k_trace<512, false, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, false>));
+  f(reinterpret_cast<const void*>(&k_trace<1024, true, true, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true, true>));
   f(reinterpret_cast<const void*>(&k_trace_rays<true>)); f(reinterpret_cast<const void*>(&k_trace_rays<false>));
 }
 }  // namespace
@@ -847,22 +862,32 @@ TracePlan trace_plan(const DevScene& sc) {
   // stack entries needed = BVH depth - 1: one pending sibling group per level above the deepest node (the root "group" has a
   // single member and the deepest nodes have no inner children); tests/test_host_bvh8.py checks the bound
   P.levels = std::max(2u, sc.stack_levels > 1u ? sc.stack_levels - 1u : 1u);
+  // ... of which the top lds_levels live in LDS and the rest in HBM (k_trace<1024, ., true, SPILL>).  A lane's stack is rarely deep
+  // (100 k triangles, 8 levels: 6.5 pushes per ray, 0.011 of them land at depth 5 or below; 1 M, 9 levels: 0.013 at depth 6 or
+  // below), but the test on every push and pop costs what the freed LDS buys back on trees whose stacks fit (profiles/README.md):
+  // spilling is for trees so deep that the stacks alone would force smaller workgroups and fewer resident waves.
+  P.lds_levels = P.levels;
+  if (E.dyn && !E.block_env) {
+    const uint32_t want = E.lds_levels_env ? E.lds_levels_env : (P.levels >= PHX_SPILL_FROM_LEVELS ? PHX_SPILL_LDS_LEVELS : P.levels);
+    P.lds_levels = std::max(2u, std::min(P.levels, want));
+  }
+  const bool spill = P.lds_levels < P.levels;
   // nodelets staged in LDS: whatever the per-lane stacks leave of the workgroup's share of the CU's 160 KB at full occupancy
   // (32 waves per CU); 9 (root + one level) when the stacks alone do not fit, and occupancy then follows from the LDS
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
     uint32_t ntop_req = E.ntop_env;
     if (!ntop_req) {
-      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.lds_levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
       ntop_req = share > stacks + 9u * PHX_NODE_LDS_BYTES ? (share - stacks) / PHX_NODE_LDS_BYTES : 9u;
     }
     ntop_out = std::min(ntop_req, sc.num_elems);
-    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
+    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.lds_levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
     return std::min(160u * 1024u / lds_out, 2048u / blk);
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
   // exceed the CU's LDS at full occupancy) is better served by smaller workgroups, whose LDS granularity wastes less
   P.block = E.block_env ? E.block_env : (E.dyn ? 1024u : 256u);
-  if (E.block_env || !E.dyn) P.wg_per_cu = plan(P.block, P.ntop, P.lds_bytes);
+  if (E.block_env || !E.dyn || spill) P.wg_per_cu = plan(P.block, P.ntop, P.lds_bytes);  // spilling exists for 1024-thread workgroups only
   else {
     uint32_t best_waves = 0;
     for (uint32_t blk = 1024u; blk >= 256u; blk >>= 1) {
@@ -872,6 +897,7 @@ TracePlan trace_plan(const DevScene& sc) {
   }
   if (E.wg_cap > 0 && P.wg_per_cu > (uint32_t)E.wg_cap) P.wg_per_cu = (uint32_t)E.wg_cap;
   if (P.wg_per_cu == 0) P.wg_per_cu = 1;  // deeper than the LDS can hold even with 256 threads: the launch will report the error
+  P.spill_threads = spill ? sc.num_cus * P.wg_per_cu * (uint32_t)std::max(1, E.dyn_grid) * P.block : 0u;
   return P;
 }
 
@@ -879,7 +905,7 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
                   int camera_rays, uint32_t sample0) {
   const TraceEnv& E = trace_env();
   const TracePlan P = trace_plan(sc);
-  const uint32_t block = P.block, ntop = P.ntop, lds = P.lds_bytes, levels = P.levels;
+  const uint32_t block = P.block, ntop = P.ntop, lds = P.lds_bytes, levels = P.lds_levels;
   const int dyn = E.dyn;
   const int interleave = camera_rays ? E.inter0 : 0;
   const uint32_t mul = (uint32_t)std::max(1, dyn ? E.dyn_grid : (camera_rays ? E.gmul0 : E.gmul));
@@ -890,7 +916,9 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   auto go = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, interleave, ntop, levels, E.min_chunks, sample0, mul, E.target_chunks);
   };
-  if (dyn) {
+  if (dyn && P.lds_levels < P.levels) {  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
+    if (camera_rays) go(&k_trace<1024, true, true, true>); else go(&k_trace<1024, false, true, true>);
+  } else if (dyn) {
     if (camera_rays) { if (block == 256) go(&k_trace<256, true, true>); else if (block == 512) go(&k_trace<512, true, true>); else go(&k_trace<1024, true, true>); }
     else { if (block == 256) go(&k_trace<256, false, true>); else if (block == 512) go(&k_trace<512, false, true>); else go(&k_trace<1024, false, true>); }
   } else if (camera_rays) {

@@ -52,19 +52,19 @@ def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
     st = dev.stats()
     print(f"\n[config 4/{builder}] preprocess {time.time() - t0:.1f} s (tree {st['bvh_build_ms']:.0f} ms), {st['bvh_nodes']} nodes, "
           f"{st['bvh_bytes'] / 1e6:.0f} MB, depth {st['bvh_depth']}; k_trace plan: block {st['trace_block']}, "
-          f"{st['trace_ntop']} elements in LDS, {st['trace_levels']} stack levels, {st['trace_waves_per_cu']} waves/CU")
+          f"{st['trace_ntop']} elements in LDS, {st['trace_levels']} stack levels ({st['trace_lds_levels']} in LDS), {st['trace_waves_per_cu']} waves/CU")
     # (c) the launch plan this tree runs with (kernels.hip: trace_plan): consistent with the depth and with the CU's 160 KB of LDS
     assert st["triangles"] == N_TRI + 2 and st["bvh_bytes"] > 600e6
     assert 8 <= st["bvh_depth"] <= 64 and st["trace_levels"] == max(2, st["bvh_depth"] - 1)
     assert st["trace_block"] in (256, 512, 1024) and st["trace_ntop"] >= 9 and st["trace_waves_per_cu"] >= 16
-    # the 100 k soup (depth 7: 6 stack levels) stages 383 pool elements beside its stacks; a tree this deep leaves room for fewer
-    assert st["trace_levels"] >= 8 and st["trace_ntop"] < 383
-    # LDS of one workgroup: staged elements at an 80-byte stride + 8 bytes per lane and level + cursors + the 2 KB octant table
-    lds = st["trace_ntop"] * 80 + st["trace_levels"] * st["trace_block"] * 8 + 16 + 2048
+    # a tree this deep (>= 10 stack levels) keeps only the top 7 levels of the stack in LDS, the rest spills to HBM
+    assert st["trace_levels"] >= 8 and 2 <= st["trace_lds_levels"] <= st["trace_levels"] and st["trace_ntop"] < 383
+    # LDS of one workgroup: staged elements at an 80-byte stride + 8 bytes per lane and LDS level + cursors + the 2 KB octant table
+    lds = st["trace_ntop"] * 80 + st["trace_lds_levels"] * st["trace_block"] * 8 + 32 + 2048
     assert lds * (st["trace_waves_per_cu"] * 64 // st["trace_block"]) <= 160 * 1024
-    if builder == "device":  # the LBVH of this soup is the same on every run: pin the plan it gets (11 levels: the stacks alone
-        # would fill the CU's LDS at 32 waves, so the planner trades occupancy: 256-thread workgroups, 28 waves per CU)
-        assert (st["bvh_depth"], st["trace_block"], st["trace_levels"], st["trace_waves_per_cu"]) == (11, 256, 10, 28)
+    if builder == "device":  # the LBVH of this soup is the same on every run: pin the plan it gets (11 levels: all ten stack
+        # levels in LDS would force 256-thread workgroups and 28 waves per CU; with three of them in HBM it is 1024 threads, 32 waves)
+        assert (st["bvh_depth"], st["trace_block"], st["trace_levels"], st["trace_lds_levels"], st["trace_waves_per_cu"]) == (11, 1024, 10, 7, 32)
 
     # (a) stage level: 16 k random rays inside the cloud + 8 k camera rays; closest hit and any hit
     o1, d1, t1 = random_rays(16384, 41)
