@@ -50,3 +50,28 @@ def test_roofline_fractions_are_fractions():
         assert 0 < c["frac"] <= 1.0, name
         assert abs(c["frac"] - c["achieved"] / c["peak"]) < 1e-9, name
     assert roof["traffic"] > 1e9 and "GBps" in roof["algorithmic_ref_layout"] and roof["device_layout"]["bytes_per_ray"]["closest"] > 48
+
+
+def test_newest_committed_bench_record_keeps_the_contract():
+    """the newest profiles/r*_bench_full.json (written by `python bench.py` on an MI355X) carries every key of the bench contract,
+    fractions that are fractions, and the two secondary records"""
+    import glob, json
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_full.json")))
+    assert recs
+    d = json.loads(open(recs[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["vs_baseline"] is None
+    assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["traffic"] > 1e9
+    assert all(0 < c["frac"] <= 1 for c in rf["ceilings"].values()) and rf["bound"] in rf["ceilings"]
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert len(d["secondary"]) == 2 and all(s["film_finite"] and 0 < s["roofline"]["frac"] <= 1 for s in d["secondary"])
