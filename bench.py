@@ -276,8 +276,8 @@ def run_workload(xpu, scenes, triangles, width, height, spp, depth, seed, builde
     """one device, one scene, `steps` timed frames on one GPU -> (value Mrays/s, ms per step, acc, last stats, preprocess s)"""
     scene = scenes.soup(triangles, seed=1234, width=width, height=height)
     import torch
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=depth, samples_in_flight=samples_in_flight,
-                                             bvh_builder=builder, device_ordinal=torch.cuda.current_device()))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=depth, samples_in_flight=samples_in_flight,
+                                         bvh_builder=builder, device_ordinal=torch.cuda.current_device()))
     t0 = time.time(); dev.preprocess(scene); pre = time.time() - t0
     tiles = xpu.Tiles.make(width, height, 32)
     import torch  # device memory for the film, which stays in HBM inside the timed region (as in main())
@@ -342,7 +342,7 @@ def main():
     opts = xpu.Options(samples_per_pixel=args.spp, paths_per_sample=1, path_depth=args.depth,
                        device_ordinal=local_rank, samples_in_flight=args.samples_in_flight,
                        bvh_builder=args.bvh_builder)
-    dev = xpu.HipDevice.discover(opts)[0]
+    dev = xpu.HipDevice.make(opts)
     t0 = time.time()
     dev.preprocess(scene)  # flatten + BVH build + upload: outside the timed region
     preprocess_s = time.time() - t0

@@ -43,6 +43,17 @@ struct DevMaterial {
   DevLobe lobes[8];
 };
 
+// The lobe loops evaluate one of seven models per iteration, chosen by the lobe's type.  Left alone, the compiler hoists every
+// loop-invariant subexpression of EVERY model (the local-frame directions, their sines, cosines, tangents, ...) in front of the loop
+// and keeps them all alive across it: bsdf_f needed 129 VGPRs although its most expensive model needs 36, and the hoisted arithmetic ran
+// for models the material does not have.  Passing the directions through an empty asm inside the loop makes them "new" values per
+// iteration: nothing is hoisted, no instruction is emitted.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHX_PIN_V3(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z))
+#else
+#define PHX_PIN_V3(v) ((void)0)
+#endif
+
 static const double kPiD = 3.14159265358979323846;
 static const double kInvPiD = 0.318309886183790671538;
 
@@ -113,23 +124,21 @@ PHX_HD float fresnel_mix_factor(float ior, const v3& n, const v3& view /* hits.w
   const float eta = backfacing ? 1.0f / f : f;
   return osl_fresnel_dielectric(dot(view, n), eta);
 }
-// The closure list of material `m` AT THIS HIT: weights resolved — (pre * term) * weight, the order eval_closure multiplies down
-// the tree — and closures whose weight is all zero dropped (OSL's null closure), so `out.num_lobes` is what bsdf_t::lobes
-// would be.  Only called for materials with per_hit set; the others use their baked table directly.
-PHX_HD void material_at_hit(const DevMaterial& m, const v3& n, const v3& view, DevMaterial& out) {
-  out.num_lobes = 0; out.is_emitter = m.is_emitter; out.ex = m.ex; out.ey = m.ey; out.ez = m.ez; out.sheen_L5 = m.sheen_L5;
-  out.per_hit = 0; out.pad = 0;
-  for (uint32_t i = 0; i < m.num_lobes; ++i) {
-    DevLobe l = m.lobes[i];
-    if (l.fac_mode != 0u) {
-      const float fac = fresnel_mix_factor(l.fac_ior, n, view);
-      const float term = l.fac_mode == 1u ? fac : 1.0f - fac;
-      l.wx = (l.px * term) * l.wx; l.wy = (l.py * term) * l.wy; l.wz = (l.pz * term) * l.wz;
-      if (l.wx == 0.0f && l.wy == 0.0f && l.wz == 0.0f) continue;
-      l.fac_mode = 0u;
-    }
-    out.lobes[out.num_lobes++] = l;
+// The closure list of a material AT THIS HIT is its baked table with the hit-dependent weights resolved — (pre * term) * weight, the
+// order eval_closure multiplies down the tree — and closures whose weight is all zero dropped (OSL's null closure), so the number
+// of kept lobes is what bsdf_t::lobes would be.  Nothing is copied: bsdf_f / bsdf_sample resolve a lobe's weight where they use it
+// (a per-hit copy of the 576-byte material lived in scratch memory: 700 B per lane, and every material read became a flat load).
+// PERHIT = false compiles the resolution out (scenes without such materials).  `view` = hits.wi.
+template <bool PERHIT>
+PHX_HD bool lobe_weight_at_hit(const DevLobe& l, const v3& n, const v3& view, v3& w) {
+  w = v3(l.wx, l.wy, l.wz);
+  if (PERHIT && l.fac_mode != 0u) {
+    const float fac = fresnel_mix_factor(l.fac_ior, n, view);
+    const float term = l.fac_mode == 1u ? fac : 1.0f - fac;
+    w = v3((l.px * term) * l.wx, (l.py * term) * l.wy, (l.pz * term) * l.wz);
+    if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) return false;
   }
+  return true;
 }
 
 // ---- GGX ---------------------------------------------------------------------------------------
@@ -310,40 +319,60 @@ PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3&
 // bsdf_t::f, src/bsdf.cpp:113-131
 // MAXL = 1: the caller guarantees num_lobes <= 1; every lobe index is then the constant 0, so a material assembled in registers
 // (k_shade<2>: DevMatLite) never has to be addressed dynamically.  Same statements, same order, same results.
-template <bool DIFFUSE_ONLY = false, int MAXL = 8>
-PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) {
+// The tangent frame of the hit is the caller's (one per hit, shared with bsdf_sample).  wo = hits.wi (the view direction).
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
+PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const Frame& fr, const v3& wi, const v3& wo) {
   v3 out(0.0f);
   if (m.num_lobes == 0) return out;
-  const Frame fr(n);
   const float atl = dot(n, wi);
   const bool reflect = atl * dot(n, wo) > 0.0f;
   const uint32_t nl = MAXL == 1 ? 1u : m.num_lobes;
+#pragma nounroll
   for (uint32_t i = 0; i < nl; ++i) {
     const DevLobe& p = m.lobes[MAXL == 1 ? 0u : i];
-    float ignored;
-    const float e = lobe_eval<DIFFUSE_ONLY>(p, n, fr, wi, wo, m.sheen_L5, ignored);
+    v3 w;
+    if (!lobe_weight_at_hit<PERHIT>(p, n, wo, w)) continue;
     if ((reflect && (p.flags & B_REFLECT)) || (!reflect && (p.flags & B_TRANSMIT))) {
-      const v3 ew = v3(e) * v3(p.wx, p.wy, p.wz);
+      float ignored;
+      v3 wi_ = wi, wo_ = wo;
+      if (!DIFFUSE_ONLY) { PHX_PIN_V3(wi_); PHX_PIN_V3(wo_); }
+      const float e = lobe_eval<DIFFUSE_ONLY>(p, n, fr, wi_, wo_, m.sheen_L5, ignored);  // evaluated only where it is used: no side effects
+      const v3 ew = v3(e) * w;
       out = out + ew * atl;
     }
   }
   return out;
 }
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
+PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) { return bsdf_f<DIFFUSE_ONLY, MAXL, PERHIT>(m, n, Frame(n), wi, wo); }
 
-// bsdf_t::sample, src/bsdf.cpp:133-248.  Returns f (already weighted); pdf == 0 terminates.
-template <bool DIFFUSE_ONLY = false, int MAXL = 8>
-PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
+// bsdf_t::sample, src/bsdf.cpp:133-248.  Returns f (already weighted); pdf == 0 terminates.  wi = hits.wi (the view direction).
+// PERHIT: the lobes of the hit are the baked lobes whose resolved weight is not all zero, in table order (lobe_weight_at_hit):
+// `keep` has a bit per baked lobe, `lobes` counts them, and the sampled index picks the index-th KEPT lobe.
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
+PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, const Frame& fr, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
   pdf = 0.0f; sample_flags = 0; wo = v3(0.0f);
-  const uint32_t lobes = MAXL == 1 ? (m.num_lobes ? 1u : 0u) : m.num_lobes;
+  uint32_t keep = 0xffu, lobes = MAXL == 1 ? (m.num_lobes ? 1u : 0u) : m.num_lobes;
+  if (PERHIT && m.per_hit) {
+    keep = 0u; lobes = 0u;
+    for (uint32_t i = 0; i < m.num_lobes; ++i) {
+      v3 w;
+      if (lobe_weight_at_hit<true>(m.lobes[i], n, wi, w)) { keep |= 1u << i; ++lobes; }
+    }
+  }
   if (lobes == 0) return v3(0.0f);
   const float fl = (float)lobes;
   uint32_t index = (uint32_t)floorf(u1 * fl);
   if (index > lobes - 1) index = lobes - 1;
   if (MAXL == 1) index = 0;  // what the two lines above compute for lobes == 1 and u1 in [0, 1)
-  const float one_minus_epsilon = 1.0f - FLT_EPSILON;
-  const float u = fminf(u1 * fl - (float)index, one_minus_epsilon);
-  const DevLobe& p = m.lobes[MAXL == 1 ? 0u : index];
-  const Frame fr(n);
+  const float u = fminf(u1 * fl - (float)index, 1.0f - FLT_EPSILON);
+  uint32_t chosen = index;  // position of the index-th kept lobe in the baked table
+  if (PERHIT && m.per_hit) {
+    uint32_t seen = 0;
+    for (uint32_t i = 0; i < m.num_lobes; ++i)
+      if (keep & (1u << i)) { if (seen == index) chosen = i; ++seen; }
+  }
+  const DevLobe& p = m.lobes[MAXL == 1 ? 0u : chosen];
   float res = 0.0f;
   bool pdf_set = false;
   switch (DIFFUSE_ONLY ? (uint32_t)L_DIFFUSE : p.type) {
@@ -430,16 +459,23 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, con
   }
   if (!pdf_set) pdf = 0.0f;
   if (pdf == 0.0f) return v3(0.0f);
-  v3 result = v3(res) * v3(p.wx, p.wy, p.wz);
+  v3 pw;
+  (void)lobe_weight_at_hit<PERHIT>(p, n, wi, pw);
+  v3 result = v3(res) * pw;
   int matched = 1;
-  for (uint32_t i = 0; MAXL > 1 && i < lobes; ++i) {
+#pragma nounroll
+  for (uint32_t i = 0; MAXL > 1 && i < m.num_lobes; ++i) {
     const DevLobe& q = m.lobes[i];
-    if (i != index && ((p.flags & q.flags) == q.flags)) {
+    if (i != chosen && (keep & (1u << i)) && ((p.flags & q.flags) == q.flags)) {
       const bool reflect = dot(n, wi) * dot(n, wo) > 0.0f;
       if ((reflect && (q.flags & B_REFLECT)) || (!reflect && (q.flags & B_TRANSMIT))) {
         float lobe_pdf = 0.0f;
-        const float e = lobe_eval<DIFFUSE_ONLY>(q, n, fr, wi, wo, m.sheen_L5, lobe_pdf);
-        result = result + v3(e) * v3(q.wx, q.wy, q.wz);
+        v3 wi_ = wi, wo_ = wo;
+        if (!DIFFUSE_ONLY) { PHX_PIN_V3(wi_); PHX_PIN_V3(wo_); }
+        const float e = lobe_eval<DIFFUSE_ONLY>(q, n, fr, wi_, wo_, m.sheen_L5, lobe_pdf);
+        v3 qw;
+        (void)lobe_weight_at_hit<PERHIT>(q, n, wi, qw);
+        result = result + v3(e) * qw;
         pdf += lobe_pdf;
         ++matched;
       }
@@ -448,6 +484,10 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, con
   pdf /= (float)matched;
   sample_flags = p.flags;
   return result;
+}
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
+PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
+  return bsdf_sample<DIFFUSE_ONLY, MAXL, PERHIT>(m, n, Frame(n), u1, u2, wi, wo, pdf, sample_flags);
 }
 
 }  // namespace phx

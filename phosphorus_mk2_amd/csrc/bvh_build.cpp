@@ -267,7 +267,9 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     std::vector<float> sub(nn, 0.0f);
     cuts.resize(nn);
     const float CN = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f, CT = 1.0f;  // measured VALU time per node visit : per triangle test
-    static const uint32_t dp_heap_limit = getenv("PHX_DP_HEAP") ? (uint32_t)atoi(getenv("PHX_DP_HEAP")) : 128u;  // experiment: 16 = cuts within 4 levels
+    // experiment knob (16 = cuts within 4 levels), clamped: the DP tables below hold 256 heap positions and a position h < limit
+    // looks at its children 2h and 2h+1
+    static const uint32_t dp_heap_limit = (uint32_t)std::min(128, std::max(2, getenv("PHX_DP_HEAP") ? atoi(getenv("PHX_DP_HEAP")) : 128));
     struct Local {
       float best[256][9]; uint8_t split[256][9]; uint8_t done[256][9]; uint32_t node[256];
     };

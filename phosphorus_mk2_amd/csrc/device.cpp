@@ -37,6 +37,17 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
     if (e_ != hipSuccess) return fail(PHX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Entry points run on the CALLER's thread: they switch to their device and put the caller's current device back on the way out,
+// so a host that mixes several phx_devices with its own HIP / torch allocations never finds itself on another GPU.
+struct DeviceScope {
+  int prev = -1; bool ok = false;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr; size_t n = 0;
@@ -214,7 +225,8 @@ phx_device* phx_dev_make(const phx_options* options) {
     fail(PHX_ERR_NO_DEVICE, std::string("device is not gfx950: ") + p.gcnArchName);
     return nullptr;
   }
-  if (hipSetDevice(dev) != hipSuccess) { fail(PHX_ERR_DEVICE, "hipSetDevice failed"); return nullptr; }
+  DeviceScope on(dev);  // the caller's current device is restored when this returns
+  if (!on.ok) { fail(PHX_ERR_DEVICE, "hipSetDevice failed"); return nullptr; }
   phx_device* d = new (std::nothrow) phx_device();
   if (!d) { fail(PHX_ERR_OOM, "host memory allocation failed"); return nullptr; }
   d->opt = *options; d->hip_device = dev;
@@ -230,7 +242,7 @@ phx_device* phx_dev_make(const phx_options* options) {
 
 void phx_dev_destroy(phx_device* dev) {
   if (!dev) return;
-  (void)hipSetDevice(dev->hip_device);
+  DeviceScope on(dev->hip_device);
   delete dev;
 }
 
@@ -244,7 +256,8 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if (s->camera.film_width == 0 || s->camera.film_height == 0 || s->camera.film_width > 65535 || s->camera.film_height > 65535)
     return fail(PHX_ERR_ARG, "film size out of range");
   if (s->environment_material >= (int32_t)s->num_materials) return fail(PHX_ERR_ARG, "environment material out of range");
-  HIPCHK(hipSetDevice(d->hip_device));
+  DeviceScope on(d->hip_device);
+  if (!on.ok) return fail(PHX_ERR_DEVICE, "hipSetDevice failed");
   const auto t_pre0 = std::chrono::steady_clock::now();
 
   // triangles in scene_t::triangles() order: mesh order x face-set order (scene.cpp:58-62, mesh.cpp:118-128)
@@ -512,7 +525,8 @@ static int dev_trace_impl(phx_device* d, uint32_t n, const float* o, const float
                   float* t, float* u, float* v, uint32_t* prim, uint8_t* hit) {
   if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "trace before preprocess");
   if (n == 0) return PHX_OK;
-  HIPCHK(hipSetDevice(d->hip_device));
+  DeviceScope on(d->hip_device);
+  if (!on.ok) return fail(PHX_ERR_DEVICE, "hipSetDevice failed");
   std::vector<float4> ro(n), rd(n), hh(n);
   for (uint32_t i = 0; i < n; ++i) {
     ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], 0.0f);
@@ -547,7 +561,8 @@ static int dev_bsdf_f_impl(phx_device* d, uint32_t material, uint32_t n, const f
   if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "bsdf_f before preprocess");
   if (material >= d->num_materials) return fail(PHX_ERR_ARG, "material out of range");
   if (n == 0) return PHX_OK;
-  HIPCHK(hipSetDevice(d->hip_device));
+  DeviceScope on(d->hip_device);
+  if (!on.ok) return fail(PHX_ERR_DEVICE, "hipSetDevice failed");
   DevBuf<float> a, b, c, o; int rc;
   if ((rc = kat_upload(n3, 3 * (size_t)n, a)) || (rc = kat_upload(wi3, 3 * (size_t)n, b)) || (rc = kat_upload(wo3, 3 * (size_t)n, c)) || (rc = o.alloc(3 * (size_t)n))) return rc;
   launch_bsdf_f(d->stream, d->d_materials.p + material, n, a.p, b.p, c.p, o.p);
@@ -566,7 +581,8 @@ static int dev_bsdf_sample_impl(phx_device* d, uint32_t material, uint32_t n, co
   if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "bsdf_sample before preprocess");
   if (material >= d->num_materials) return fail(PHX_ERR_ARG, "material out of range");
   if (n == 0) return PHX_OK;
-  HIPCHK(hipSetDevice(d->hip_device));
+  DeviceScope on(d->hip_device);
+  if (!on.ok) return fail(PHX_ERR_DEVICE, "hipSetDevice failed");
   DevBuf<float> a, b, c, wo, f, p; DevBuf<uint32_t> fl; int rc;
   if ((rc = kat_upload(n3, 3 * (size_t)n, a)) || (rc = kat_upload(wi3, 3 * (size_t)n, b)) || (rc = kat_upload(u2, 2 * (size_t)n, c)) ||
       (rc = wo.alloc(3 * (size_t)n)) || (rc = f.alloc(3 * (size_t)n)) || (rc = p.alloc(n)) || (rc = fl.alloc(n))) return rc;

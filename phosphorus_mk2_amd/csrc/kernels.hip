@@ -48,6 +48,7 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 template <int SHADE_BLOCK>
 __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, bool want_b, uint32_t* counter_b, uint32_t* lds /* [2 * (waves + 1)] */,
                                               uint32_t& at_a, uint32_t& at_b) {
+  static_assert(SHADE_BLOCK >= 128 && SHADE_BLOCK % 64 == 0, "block_append2: wave 0 sums queue A, wave 1 queue B");
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = SHADE_BLOCK >> 6;
   const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b);
   uint32_t* cnt_a = lds; uint32_t* cnt_b = lds + nwaves + 1;
@@ -56,6 +57,7 @@ __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, 
   if (lane == 0 && wave < 2) {
     uint32_t* cnt = wave == 0 ? cnt_a : cnt_b;
     uint32_t total = 0;
+#pragma nounroll
     for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = cnt[w]; cnt[w] = total; total += c; }
     cnt[nwaves] = total ? atomicAdd(wave == 0 ? counter_a : counter_b, total) : 0u;
   }
@@ -540,40 +542,23 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
   return (float)0.212671 * c.x + (float)0.715160 * c.y + (float)0.072169 * c.z;
 }
 
-template <int MATS /* 0 any closure; 3 any closure, none with hit-dependent weights (every material read stays a global load: with the
-                      per-hit copy in scratch the material pointer is of either address space and every read a flat load);
-                      1 Lambert lobes only; 2 at most one Lambert lobe per material (DevScene::diffuse_only, any_per_hit) */,
+// The Lambert-only scenes (the soups, the Cornell box): shade + NEE + integrate of one path per thread in one go; HBM-stream bound.
+// Scenes with other closures go through k_shade_g below.
+template <int MATS /* 1 Lambert lobes only; 2 at most one Lambert lobe per material (DevScene::diffuse_only) */,
           bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
-__global__ void __launch_bounds__((MATS == 1 || MATS == 2) ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu((MATS == 1 || MATS == 2) ? 4 : PHX_SHADE_WAVES_G, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
-  constexpr bool DIFFUSE_ONLY = MATS == 1 || MATS == 2;
+__global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+  static_assert(MATS == 1 || MATS == 2, "general closures: k_shade_g");
+  constexpr bool DIFFUSE_ONLY = true;
   constexpr int MAXL = MATS == 2 ? 1 : 8;
-  constexpr int PHX_SHADE_BLOCK = DIFFUSE_ONLY ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
+  constexpr int PHX_SHADE_BLOCK = PHX_SHADE_BLOCK_D;
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
-  uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
+  const uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
   if (i == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0; }  // the next k_trace pulls its chunks from here
+  // One block per workgroup, grid sized for the queue's capacity.  (A fixed grid walking the queue in a loop — what k_shade_g does —
+  // costs this kernel its occupancy: whatever is loop-invariant gets hoisted and held in registers, 51-61 VGPRs become 73-82, and
+  // 1024-thread workgroups need <= 64 to run two per CU.)
   if (blockIdx.x * PHX_SHADE_BLOCK >= count) return;
-  if (!DIFFUSE_ONLY) {
-    // Bucket the workgroup's 512 hits by material before shading them — what deferred_shading_kernel_t does per
-    // 1024-slot stream (deferred_t::material, deferred_shading_kernel.hpp:9-33, 63) — so that a wave evaluates a few
-    // closure recipes instead of up to 64 different ones.  Counting sort through LDS on (material mod 32).
-    __shared__ uint32_t bucket[33];
-    __shared__ uint16_t perm[PHX_SHADE_BLOCK];
-    if (threadIdx.x < 33) bucket[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t key = 32u;  // misses and out-of-range slots go last
-    if (i < count) {
-      const uint32_t tri = f2u(pb.hit[i].w);
-      if (tri != 0xffffffffu) key = sc.tris[tri].material & 31u;
-    }
-    const uint32_t rank = atomicAdd(&bucket[key], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t acc = 0; for (int k = 0; k < 33; ++k) { const uint32_t c = bucket[k]; bucket[k] = acc; acc += c; } }
-    __syncthreads();
-    perm[bucket[key] + rank] = (uint16_t)threadIdx.x;
-    __syncthreads();
-    i = blockIdx.x * PHX_SHADE_BLOCK + perm[threadIdx.x];
-  }
   const bool live = i < count;
   bool alive = false, want_shadow = false, masked = false;
   uint32_t path = 0, next_specular = 0;
@@ -622,7 +607,6 @@ __global__ void __launch_bounds__((MATS == 1 || MATS == 2) ? PHX_SHADE_BLOCK_D :
         mh.ex = ml.ex; mh.ey = ml.ey; mh.ez = ml.ez; mh.sheen_L5 = 0.0f;
         mp = &mh;
       }
-      if (MATS == 0 && mp->per_hit) { material_at_hit(*mp, n, wo, mh); mp = &mh; }
       const DevMaterial& m = *mp;
       if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
       const v3 e(m.ex, m.ey, m.ez);
@@ -725,6 +709,233 @@ __global__ void __launch_bounds__((MATS == 1 || MATS == 2) ? PHX_SHADE_BLOCK_D :
   (void)masked;  // rays_masked = rays_closest - rays_shadow: every shaded slot yields a shadow ray or a masked slot
 }
 
+// ---- general closures: shade + NEE + integrate with the hits of a workgroup sorted by material ----------------------------------
+// k_shade_g replaces the round-2 k_shade<0/3> (128 VGPRs, 160-700 B of scratch per lane, 4 waves per SIMD: the weakest kernel of the
+// repo).  What changed, and why:
+//   * no per-hit copy of the material.  A glass hit used to resolve its closure weights into a private 576-byte DevMaterial (scratch
+//     memory, and every material read a flat load); now bsdf_f / bsdf_sample resolve a lobe's weight where they use it (bsdf.h).
+//   * the two halves of a step no longer overlap in registers: the NEE ray is appended to the shadow queue BEFORE roulette and BSDF
+//     sampling start, so its origin / direction / beta*Li are dead by then (the seam the reference has between light_sampler_t and
+//     integrator_t, spt.hpp:95-149 / 161-328); the hit's tangent frame is built once and used by both.
+//   * a workgroup sorts a WINDOW of BLOCK x ITEMS hits by material, not BLOCK: with 16 recipes assigned round-robin a 512-hit
+//     bucket sort left 2-3 materials in every wave; a window of 4096 leaves most waves with one (deferred_shading_kernel_t buckets
+//     a 1024-slot stream per material for the same reason, deferred_shading_kernel.hpp:9-33, 63).
+//   * a fixed grid walks the queue (see k_shade).
+#ifndef PHX_SHADE_ITEMS_G
+#define PHX_SHADE_ITEMS_G 8
+#endif
+#define PHX_SHADE_BUCKETS 64  /* sort key = material mod 64; then the misses; slots past the end of the queue go last */
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_append1(bool want, uint32_t* counter, uint32_t* lds /* [waves + 1] */) {
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = BLOCK >> 6;
+  const unsigned long long mask = __ballot(want);
+  if (lane == 0) lds[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+#pragma nounroll
+    for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = lds[w]; lds[w] = total; total += c; }
+    lds[nwaves] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  return lds[nwaves] + lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
+__global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
+  constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
+  static_assert(WINDOW <= 65536 && BLOCK >= NB + 2 && NB == 64, "perm holds 16-bit positions; one wave scans the NB material buckets");
+  __shared__ uint32_t lds_s[(BLOCK >> 6) + 1], lds_r[(BLOCK >> 6) + 1];
+  __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
+  __shared__ uint16_t perm[WINDOW];
+  const uint32_t count = pb.counters[q * CNT_STRIDE];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0; }  // the next k_trace pulls its chunks from here
+  for (uint32_t base = blockIdx.x * WINDOW; base < count; base += gridDim.x * WINDOW) {
+    // ---- counting sort of the window by material, through LDS
+    if (threadIdx.x < NB + 2) bucket[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t keys[ITEMS], ranks[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const uint32_t i = base + k * BLOCK + threadIdx.x;
+      uint32_t key = NB + 1u;
+      if (i < count) {
+        const uint32_t tri = f2u(pb.hit[i].w);
+        key = tri != 0xffffffffu ? (sc.tris[tri].material & (NB - 1u)) : (uint32_t)NB;
+      }
+      keys[k] = key;
+      ranks[k] = atomicAdd(&bucket[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the bucket counts by one wave
+      const uint32_t c = bucket[threadIdx.x];
+      uint32_t incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += up; }
+      bucket[threadIdx.x] = incl - c;
+      if (threadIdx.x == 63) { const uint32_t misses = bucket[NB]; bucket[NB] = incl; bucket[NB + 1] = incl + misses; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) perm[bucket[keys[k]] + ranks[k]] = (uint16_t)(k * BLOCK + threadIdx.x);
+    __syncthreads();
+    // ---- the window in sorted order: wave w of round k shades sorted positions [k * BLOCK + 64 w, + 64)
+    for (int k = 0; k < ITEMS; ++k) {
+      if (base + (uint32_t)k * BLOCK >= count) break;  // workgroup-uniform: the slots past the end of the queue sort behind every live one
+      const uint32_t i = base + perm[k * BLOCK + threadIdx.x];
+      const bool live = i < count;
+      // Live ranges are kept short on purpose (the kernel is register-bound: 128 VGPRs as one block of code): radiance and the
+      // normals channel are written as soon as the hit is known; the light's record is re-read after the closure evaluation instead
+      // of being held across it; the NEE ray is in its queue before roulette and BSDF sampling start.
+      bool alive = false, want_shadow = false, hit_surface = false;
+      uint32_t path = 0, depth = 0, key = 0;
+      v3 p, n, wo, beta;
+      const DevMaterial* mp = nullptr;
+      if (live) {
+        float4 a, b, bd;
+        const float4 h = pb.hit[i];
+        if (FIRST) {
+          v3 co, cd;
+          camera_ray(sc, pb, i, sample0, co, cd);
+          a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
+          bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
+        } else {
+          a = pb.ro[q][i]; b = pb.rd[q][i];
+        }
+        const uint32_t pbits = f2u(a.w);
+        path = pbits & 0x7fffffffu;
+        const bool specular = (pbits >> 31) != 0;
+        if (!FIRST) bd = pb.pb[path];
+        beta = v3(bd.x, bd.y, bd.z);
+        depth = f2u(bd.w);
+        const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
+        const uint32_t xy = pb.pix_xy[pix];
+        key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+        const uint32_t tri = f2u(h.w);
+        const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
+        v3 add_e(0.0f); bool add_rad = false;
+        if (tri != 0xffffffffu) {
+          hit_surface = true;
+          const TriRec T = sc.tris[tri];
+          const uint32_t pm = T.material;
+          p = o + d * h.x;            // hits.p = p + wi*d
+          wo = -d;                    // hits.wi = -wi
+          n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+          mp = &sc.materials[pm & 0x7fffffffu];  // material_t::evaluate (material.cpp:419-458): the closure recipe at this hit
+          if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
+          if (depth == 0 || specular) { add_e = v3(mp->ex, mp->ey, mp->ez); add_rad = true; }  // spt.hpp:177-179
+        } else {
+          // miss: environment lighting (deferred_shading_kernel.hpp:65-70, spt.hpp:199-202); the slot is MASKED|SHADOW in the
+          // reference's shadow stream (spt.hpp:138-141): rays_masked = rays_closest - rays_shadow
+          if (sc.env_material >= 0) { const DevMaterial& m = sc.materials[sc.env_material]; add_e = v3(m.ex, m.ey, m.ez); }
+          add_rad = true;
+          if (FIRST && pb.pn) pb.pn[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        // out += beta * e with the beta the ray arrived with.  Radiance is only read-modified-written when this step adds something:
+        // with e == 0 and a finite beta `out` is unchanged bit for bit (it is never -0)
+        if (FIRST) {  // r = 0 + beta * e: every path's radiance is written here, nothing is read
+          const v3 rad = v3(0.0f) + beta * add_e;
+          pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+        } else if (add_rad && !(isfinite(beta.x) && isfinite(beta.y) && isfinite(beta.z) && add_e.x == 0.0f && add_e.y == 0.0f && add_e.z == 0.0f)) {
+          const float4 rr = pb.pr[path];
+          const v3 rad = v3(rr.x, rr.y, rr.z) + beta * add_e;
+          pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+        }
+      }
+      // the hit's tangent frame (orthogonal_base_t): once per hit, for the NEE evaluation and the BSDF sample
+      const Frame fr(hit_surface ? n : v3(0.0f, 1.0f, 0.0f));
+      // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
+      {
+        v3 sh_o, sh_d, contrib; float sh_t = 0.0f;
+        if (hit_surface) {
+          const uint32_t b0 = depth * DIMS_PER_STEP;
+          const float pick = draw_f32(key, b0 + DIM_LIGHT_PICK), lu = draw_f32(key, b0 + DIM_LIGHT_U), lv = draw_f32(key, b0 + DIM_LIGHT_V);
+          const float nlf = (float)sc.num_lights;
+          uint32_t l = (uint32_t)floorf(pick * nlf);
+          if (l > sc.num_lights - 1) l = sc.num_lights - 1;
+          const uint32_t ltris = sc.lights[l].num_tris;
+          const float numf = (float)ltris;
+          uint32_t ti = (uint32_t)floorf(lu * numf);  // uniform by index (light.cpp:55), pdf = 1/area
+          if (ti > ltris - 1) ti = ltris - 1;
+          const float remapped = fminf(lu * numf - (float)ti, 1.0f - FLT_EPSILON);
+          uint32_t lt = sc.lights[l].first_tri + ti;
+          const float x = sqrtf(remapped);
+          const float bu = 1 - x, bv = lv * x;     // triangle_t::sample, mesh.cpp:318-324
+          {
+            const DevLightTri& LT = sc.light_tris[lt];
+            const v3 la(LT.ax, LT.ay, LT.az), lb(LT.bx, LT.by, LT.bz), lc(LT.cx, LT.cy, LT.cz);
+            const v3 P = bu * la + bv * lb + (1 - bu - bv) * lc;
+            sh_o = v3(p.x + n.x * 0.0001f, p.y + n.y * 0.0001f, p.z + n.z * 0.0001f);
+            sh_d = P - sh_o;
+          }
+          const float l2 = sdot(sh_d, sh_d);
+          sh_t = sqrtf(l2) - 0.0001f;
+          const float oolen = 1.0f / sqrtf(l2);
+          sh_d = v3(sh_d.x * oolen, sh_d.y * oolen, sh_d.z * oolen);
+          if (sdot(n, sh_d) >= 0.0f) {
+            // li(), spt.hpp:212-255 — evaluated before the occlusion test; k_trace adds it if the ray is unoccluded
+            const v3 f = bsdf_f<false, 8, PERHIT>(*mp, n, fr, sh_d, wo);
+            // the light's record again (L1-resident), behind an empty asm so that the first read is not kept alive across bsdf_f
+            asm volatile("" : "+v"(l), "+v"(lt));
+            const DevLight& L = sc.lights[l];
+            const DevLightTri& LT = sc.light_tris[lt];
+            const v3 ln = LT.smooth ? shading_normal(sc, LT.prim, true, v3(LT.bx - LT.ax, LT.by - LT.ay, LT.bz - LT.az), v3(LT.cx - LT.ax, LT.cy - LT.ay, LT.cz - LT.az), bu, bv)
+                                    : v3(LT.nx, LT.ny, LT.nz);
+            const v3 le(L.ex, L.ey, L.ez);
+            const float pdf = L.lpdf * sh_t * sh_t / fabsf(dot(ln, -sh_d));
+            const v3 li = ((le * 4.0f) * f) * (1.0f / pdf);
+            contrib = beta * li;
+            want_shadow = true;
+          }
+        }
+        const uint32_t ns = block_append1<BLOCK>(want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_s);
+        if (want_shadow) {
+          pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
+          pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
+          pb.sc[ns] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+        }
+      }
+      // ---- integrate: ++depth, russian roulette, bsdf sampling (spt.hpp:188-190, 257-328)
+      {
+        v3 nxt_d; uint32_t next_specular = 0; float off = 0.0f;
+        if (hit_surface) {
+          depth += 1;
+          float wgt = 1.0f;
+          alive = depth < sc.max_depth;
+          if (alive && depth >= 3) {
+            const float qq = fmaxf(0.05f, 1.0f - luminance(beta));
+            const float xi = draw_f32(key, (depth - 1u) * DIMS_PER_STEP + DIM_RR);
+            alive = xi >= qq;
+            if (alive) wgt = (1.0f / (1.0f - qq));
+          }
+          beta = beta * wgt;
+          if (alive) {
+            const uint32_t b1 = (depth - 1u) * DIMS_PER_STEP;
+            float pdf; uint32_t fl;
+            const v3 f = bsdf_sample<false, 8, PERHIT>(*mp, n, fr, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, nxt_d, pdf, fl);
+            if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) {
+              alive = false;
+            } else {
+              const float weight = dot(n, nxt_d);
+              beta = beta * (f * (fabsf(weight) / pdf));
+              off = (weight < 0.0f) ? -0.0001f : 0.0001f;
+              next_specular = (fl & B_SPECULAR) ? 1u : 0u;
+            }
+          }
+        }
+        if (alive) pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));  // only the next shade of a surviving path reads it
+        const uint32_t no = block_append1<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], lds_r);
+        if (alive) {
+          const v3 nxt_o = p + n * off;
+          pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
+          pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
+        }
+      }
+    }
+    __syncthreads();  // perm and bucket are rewritten by the next window
+  }
+}
+
 // ---- film -------------------------------------------------------------------------------------------
 // channels.primary->add(x, y, r * (1.0f / (spp * pps))) per sample, IN SAMPLE ORDER (cpu.cpp:175-198): the sum of a pixel is
 // a serial chain, so it cannot be a lane-parallel reduction.  Radiance is stored pixel-major (pix * S + s): a 256-thread
@@ -779,24 +990,20 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_scatter_film(PassBuffers pb, floa
 }
 
 // ---- KAT kernels ------------------------------------------------------------------------------------
-__global__ void k_bsdf_f(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
+__global__ void __launch_bounds__(64) k_bsdf_f(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* wo3, float* f3) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const v3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), view(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);  // f(wi = to the light, wo = hits.wi)
-  DevMaterial mh; const DevMaterial* mp = mat;
-  if (mat->per_hit) { material_at_hit(*mat, nn, view, mh); mp = &mh; }
-  const v3 f = bsdf_f(*mp, nn, v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), view);
+  const v3 f = bsdf_f<false, 8, true>(*mat, nn, v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), view);
   f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
 }
-__global__ void k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* u2,
+__global__ void __launch_bounds__(64) k_bsdf_sample(const DevMaterial* mat, uint32_t n, const float* n3, const float* wi3, const float* u2,
                               float* wo3, float* f3, float* pdf, uint32_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   v3 wo; float p; uint32_t fl;
   const v3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), view(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);  // sample(u, wi = hits.wi)
-  DevMaterial mh; const DevMaterial* mp = mat;
-  if (mat->per_hit) { material_at_hit(*mat, nn, view, mh); mp = &mh; }
-  v3 f = bsdf_sample(*mp, nn, u2[2 * i], u2[2 * i + 1], view, wo, p, fl);
+  v3 f = bsdf_sample<false, 8, true>(*mat, nn, u2[2 * i], u2[2 * i + 1], view, wo, p, fl);
   if (p == 0.0f) { wo = v3(0.0f); f = v3(0.0f); fl = 0; }
   wo3[3 * i] = wo.x; wo3[3 * i + 1] = wo.y; wo3[3 * i + 2] = wo.z;
   f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z; pdf[i] = p; flags[i] = fl;
@@ -814,12 +1021,17 @@ struct TraceEnv {
 };
 const TraceEnv& trace_env() {
   static const TraceEnv e = [] {
-    auto geti = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+    // knobs are experiment switches, but a typo must not become a launch shape the kernels were never built for: negative values
+    // fall back to the default and the workgroup size has to be one the kernels are instantiated for
+    auto geti = [](const char* n, int d) { const char* v = getenv(n); const int x = v ? atoi(v) : d; return x < 0 ? d : x; };
     TraceEnv t;
     t.gmul = geti("PHX_TRACE_GRID", 4); t.gmul0 = geti("PHX_TRACE_GRID0", 16); t.inter0 = geti("PHX_TRACE_INTER0", 1);
     t.refill = (uint32_t)geti("PHX_REFILL", 12); t.dyn = geti("PHX_TRACE_DYN", 1); t.dyn_grid = geti("PHX_TRACE_DYN_GRID", 1);
     // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
     t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
+    if (t.block_env != 0 && t.block_env != 256 && t.block_env != 512 && t.block_env != 1024) t.block_env = 0;
+    if (t.lds_levels_env > PHX_MAX_BVH_DEPTH) t.lds_levels_env = 0;
+    if (t.refill < 1 || t.refill > 64) t.refill = 12;
     t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
     t.lds_levels_env = (uint32_t)geti("PHX_LDS_LEVELS", 0);  // stack levels kept in LDS (0 = chosen by trace_plan)
     t.wg_cap = geti("PHX_TRACE_WG_CAP", 0);  // experiment: at most this many k_trace workgroups per CU (leaves wave slots to another stream)
@@ -927,21 +1139,33 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
     if (block == 256) go(&k_trace<256, false, false>); else if (block == 512) go(&k_trace<512, false, false>); else go(&k_trace<1024, false, false>);
   }
 }
+// k_shade / k_shade_g walk the queue with a fixed grid: PHX_SHADE_GRID workgroups per resident slot (never more than the queue's
+// capacity needs)
+static uint32_t shade_grid(const DevScene& sc, uint32_t capacity, uint32_t per_wg, uint32_t block) {
+  static const int mul = [] { const char* v = getenv("PHX_SHADE_GRID"); const int x = v ? atoi(v) : 4; return x < 1 ? 4 : x; }();
+  const uint32_t resident = sc.num_cus * (2048u / block);
+  const uint32_t need = (capacity + per_wg - 1) / per_wg;
+  return std::max(1u, std::min(need, resident * (uint32_t)mul));
+}
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays) {
-  const uint32_t sb = sc.diffuse_only ? PHX_SHADE_BLOCK_D : PHX_SHADE_BLOCK_G;
-  const dim3 g((capacity + sb - 1) / sb), b(sb);
-  if (sc.diffuse_only == 2) {
-    if (camera_rays) hipLaunchKernelGGL((k_shade<2, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
-    else hipLaunchKernelGGL((k_shade<2, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
-  } else if (sc.diffuse_only) {
-    if (camera_rays) hipLaunchKernelGGL((k_shade<1, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
-    else hipLaunchKernelGGL((k_shade<1, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
-  } else if (sc.any_per_hit) {
-    if (camera_rays) hipLaunchKernelGGL((k_shade<0, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
-    else hipLaunchKernelGGL((k_shade<0, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+  if (sc.diffuse_only) {
+    const dim3 g((capacity + PHX_SHADE_BLOCK_D - 1) / PHX_SHADE_BLOCK_D), b(PHX_SHADE_BLOCK_D);
+    if (sc.diffuse_only == 2) {
+      if (camera_rays) hipLaunchKernelGGL((k_shade<2, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+      else hipLaunchKernelGGL((k_shade<2, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    } else {
+      if (camera_rays) hipLaunchKernelGGL((k_shade<1, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+      else hipLaunchKernelGGL((k_shade<1, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    }
+    return;
+  }
+  const dim3 g(shade_grid(sc, capacity, PHX_SHADE_BLOCK_G * PHX_SHADE_ITEMS_G, PHX_SHADE_BLOCK_G)), b(PHX_SHADE_BLOCK_G);
+  if (sc.any_per_hit) {
+    if (camera_rays) hipLaunchKernelGGL((k_shade_g<true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade_g<true, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   } else {
-    if (camera_rays) hipLaunchKernelGGL((k_shade<3, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
-    else hipLaunchKernelGGL((k_shade<3, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    if (camera_rays) hipLaunchKernelGGL((k_shade_g<false, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else hipLaunchKernelGGL((k_shade_g<false, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   }
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {

@@ -14,8 +14,13 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PHX_HD __host__ __device__ __forceinline__
+// The binary64 kernels below are real functions on the device, not inlined into every lobe model that uses them: inlined, their
+// 40 polynomial coefficients (register pairs: a 64-bit literal cannot be an instruction operand) were hoisted in front of the lobe
+// loops of bsdf_f / bsdf_sample and stayed alive across them - 46 VGPRs of constants in a kernel capped at 128.
+#define PHX_HD_CALL inline __host__ __device__ __attribute__((noinline))
 #else
 #define PHX_HD inline
+#define PHX_HD_CALL inline
 #endif
 
 namespace phx {
@@ -67,7 +72,8 @@ PHX_HD double rint_small(double x) { const double big = 6755399441055744.0; retu
 PHX_HD double u64_as_double(uint64_t u) { union { uint64_t u; double d; } c; c.u = u; return c.d; }
 PHX_HD uint64_t double_as_u64(double d) { union { uint64_t u; double d; } c; c.d = d; return c.u; }
 
-PHX_HD void sincos_d(double x, double* s, double* c) {
+struct sincos_t { double s, c; };
+PHX_HD_CALL sincos_t sincos_d(double x) {  // by value: out-pointers of a real function would be stack slots
   const double two_over_pi = 6.36619772367581382433e-01;
   const double pio2_hi = 1.57079632679489655800e+00;
   const double pio2_lo = 6.12323399573676603587e-17;
@@ -89,9 +95,9 @@ PHX_HD void sincos_d(double x, double* s, double* c) {
   else if (q == 1) { ss = cr; cc = -sr; }
   else if (q == 2) { ss = -sr; cc = -cr; }
   else { ss = -cr; cc = sr; }
-  *s = ss; *c = cc;
+  return sincos_t{ss, cc};
 }
-PHX_HD double exp_d(double x) {
+PHX_HD_CALL double exp_d(double x) {
   const double inv_ln2 = 1.44269504088896338700e+00;
   const double ln2_hi = 6.93147180369123816490e-01;
   const double ln2_lo = 1.90821492927058770002e-10;
@@ -120,7 +126,7 @@ PHX_HD double exp_d(double x) {
   double s2 = u64_as_double((uint64_t)(1023 + k2) << 52);
   return p * s1 * s2;
 }
-PHX_HD double log_d(double x) {
+PHX_HD_CALL double log_d(double x) {
   const double ln2_hi = 6.93147180369123816490e-01;
   const double ln2_lo = 1.90821492927058770002e-10;
   uint64_t u = double_as_u64(x);
@@ -149,7 +155,7 @@ PHX_HD double log_d(double x) {
   double ed = (double)e;
   return fma(ed, ln2_hi, fma(ed, ln2_lo, lm));
 }
-PHX_HD void sincosf_(float x, float* s, float* c) { double sd, cd; sincos_d((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd; }
+PHX_HD void sincosf_(float x, float* s, float* c) { const sincos_t r = sincos_d((double)x); *s = (float)r.s; *c = (float)r.c; }
 PHX_HD float expf_(float x) {
   if (x != x) return x;
   if (x > 89.0f) return INFINITY;

@@ -328,10 +328,12 @@ def render_on(devices, scene_desc, seed=1, normals=False, tile_size=32, native_s
 def render(scene_desc, spp=16, pps=1, depth=9, seed=1, normals=False, tile_size=32, rank=0, world=1, callback_tiles=False,
            samples_in_flight=0, tiles_per_batch=0, native_sink=False, bvh_builder="auto"):
     """Convenience: the call sequence of session_t::render (plugins/blender/session.cpp:73-94):
-    discover -> preprocess -> tiles_t::make -> start -> join.  Returns (film array HxWxC, stats)."""
+    make -> preprocess -> tiles_t::make -> start -> join on ONE device.  Returns (film array HxWxC, stats)."""
     opts = Options(samples_per_pixel=spp, paths_per_sample=pps, path_depth=depth, samples_in_flight=samples_in_flight,
                    tiles_per_batch=tiles_per_batch, bvh_builder=bvh_builder)
-    dev = HipDevice.discover(opts)[0]
+    # ONE device, on the caller's current GPU (device_ordinal -1): discover() is for hosts that drive every GPU (render_on) and
+    # would build a context, a stream and the kernel attributes on each of them only to use the first
+    dev = HipDevice.make(opts)
     try:
         dev.preprocess(scene_desc)
         W, H = scene_desc.camera.width, scene_desc.camera.height

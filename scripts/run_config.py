@@ -36,7 +36,7 @@ elif a.scene == "showroom":
 else:
     sc = scenes.cornell(a.width, a.height)
 t_scene = time.time() - t0
-dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=a.spp, paths_per_sample=1, path_depth=9, bvh_builder=a.builder))[0]
+dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=a.spp, paths_per_sample=1, path_depth=9, bvh_builder=a.builder))
 t0 = time.time()
 dev.preprocess(sc)
 t_pre = time.time() - t0

@@ -1,3 +1,5 @@
+#!/bin/bash
+# Run ON the GPU box: the distributed code path at world 1, then rank 0's share of the bench frame at world 1/2/4/8 (one GPU).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 python3 $R/bench.py --force-dist --steps 2 --warmup 1 > $R/gpurun_out/force_dist.json 2> $R/gpurun_out/force_dist.err || { echo force-dist failed; tail -5 $R/gpurun_out/force_dist.err; exit 1; }
 python3 -c "import json; d=json.loads(open('$R/gpurun_out/force_dist.json').read().strip().splitlines()[-1]); print('force-dist', round(d['value']), d['ms_per_step'], d['config']['film_collective'])"

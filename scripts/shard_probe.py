@@ -8,7 +8,7 @@ from phosphorus_mk2_amd import scenes, xpu
 xpu.load_library()
 W, H, SPP = 1280, 720, 256
 scene = scenes.soup(100000, seed=1234, width=W, height=H)
-dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=SPP, paths_per_sample=1, path_depth=9))[0]
+dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=SPP, paths_per_sample=1, path_depth=9))
 dev.preprocess(scene)
 film = xpu.Film(W, H, 4, False)
 WORLDS = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [1, 2, 4, 8]

@@ -14,7 +14,7 @@ def free_bytes():
     return f.value
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 scs = [scenes.soup(20000, width=320, height=192), scenes.cornell(256, 256), scenes.multi_material_soup(5000, width=192, height=128)]
-dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=8, paths_per_sample=1))[0]
+dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=8, paths_per_sample=1))
 ref, t0, f0 = {}, time.time(), None
 for k in range(frames):
     s = scs[k % 3]

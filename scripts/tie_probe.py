@@ -6,7 +6,7 @@ xpu.load_library()
 sc = scenes.soup(100000, width=64, height=64)
 devs = []
 for b in ("host", "device"):
-    d = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=1, paths_per_sample=1, bvh_builder=b))[0]
+    d = xpu.HipDevice.make(xpu.Options(samples_per_pixel=1, paths_per_sample=1, bvh_builder=b))
     d.preprocess(sc); devs.append(d)
 tot = 0; bad = 0
 for it in range(40):

@@ -101,3 +101,42 @@ def test_no_silent_cpu_fallback(lib):
     o.host_only = 1
     assert lib.phx_discover(C.byref(o), C.byref(n)) == 0 and n.value == 0  # --no-gpu is not an error
     assert lib.phx_dev_preprocess(None, None) != 0 and lib.phx_dev_join(None) != 0
+
+
+def test_render_makes_one_device_on_a_multi_gpu_box(monkeypatch):
+    """On a box with several GPUs render() (and every single-device script) makes exactly ONE device, with device_ordinal -1 =
+    the caller's current GPU; discover() is what makes one per GPU — or only the one asked for."""
+    from phosphorus_mk2_amd import scenes, xpu
+
+    class FakeLib:
+        def phx_discover(self, opts, n):
+            n._obj.value = 4
+            return 0
+
+        def phx_last_error(self):
+            return b""
+
+    made = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_make(options):
+        made.append(options.device_ordinal)
+        raise Stop()
+
+    monkeypatch.setattr(xpu, "load_library", lambda: FakeLib())
+    monkeypatch.setattr(xpu.HipDevice, "make", staticmethod(fake_make))
+    with pytest.raises(Stop):
+        xpu.render(scenes.cornell(32, 32), spp=1)
+    assert made == [-1]
+    made.clear()
+
+    def record_make(options):
+        made.append(options.device_ordinal)
+        return object()
+
+    monkeypatch.setattr(xpu.HipDevice, "make", staticmethod(record_make))
+    assert len(xpu.HipDevice.discover(xpu.Options())) == 4 and made == [0, 1, 2, 3]
+    made.clear()
+    assert len(xpu.HipDevice.discover(xpu.Options(device_ordinal=2))) == 1 and made == [2]

@@ -46,7 +46,7 @@ def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
     from phosphorus_mk2_amd import xpu
     xpu.load_library()
     sc, O = c4
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=SPP, paths_per_sample=1, path_depth=9, bvh_builder=builder))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=SPP, paths_per_sample=1, path_depth=9, bvh_builder=builder))
     t0 = time.time()
     dev.preprocess(sc)
     st = dev.stats()

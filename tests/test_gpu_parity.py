@@ -20,7 +20,7 @@ def xpu():
 
 
 def _device(xpu, scene, spp=4, depth=9):
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=depth))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=depth))
     dev.preprocess(scene)
     return dev
 
@@ -127,7 +127,7 @@ def test_depth_pps_and_channel_options_match_oracle(xpu, orc, depth, pps, compon
     from phosphorus_mk2_amd import scenes
     sc = scenes.cornell(48, 40)
     opts = xpu.Options(samples_per_pixel=5, paths_per_sample=pps, path_depth=depth, samples_in_flight=2)  # 3 passes: 2 + 2 + 1
-    dev = xpu.HipDevice.discover(opts)[0]
+    dev = xpu.HipDevice.make(opts)
     dev.preprocess(sc)
     film = xpu.Film(48, 40, components)
     dev.start(sc, xpu.FrameState(8, xpu.Tiles.make(48, 40, 32), film))
@@ -278,7 +278,7 @@ def test_device_built_bvh_matches_host_built(xpu, orc, name, n):
     from phosphorus_mk2_amd import scenes
     sc = {"cornell": lambda: scenes.cornell(64, 64), "soup": lambda: scenes.soup(n, width=64, height=64),
           "blobs": lambda: scenes.smooth_blobs(64, 64)}[name]()
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder="device"))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder="device"))
     dev.preprocess(sc)
     O = orc.Oracle(sc, spp=1)
     o, d, tm = random_rays(40000, 23)
@@ -307,7 +307,7 @@ def test_stress_geometry(xpu, orc, builder):
     from phosphorus_mk2_amd import scenes
     from test_host_bvh8 import check_hits_modulo_ties, stress_rays
     sc = scenes.stress()
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder=builder))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder=builder))
     dev.preprocess(sc)
     O = orc.Oracle(sc, spp=1)
     o, d, tm = stress_rays(sc, 8000, 5)
@@ -337,7 +337,7 @@ def test_showroom_meshes_match_oracle(xpu, orc, builder):
     from phosphorus_mk2_amd import scenes
     from test_host_bvh8 import stress_rays
     sc = scenes.showroom(20000, width=160, height=96, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder=builder))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1, bvh_builder=builder))
     dev.preprocess(sc)
     O = orc.Oracle(sc, spp=1)
     o, d, tm = stress_rays(sc, 6000, 11)
@@ -436,7 +436,7 @@ def test_hybrid_cpu_gpu_share_one_tile_queue(xpu, orc):
                 film.data[y:y + h, x:x + w, :] = part[y:y + h, x:x + w, :]
             cpu_tiles.append(t)
 
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=4, paths_per_sample=1, tiles_per_batch=2))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1, tiles_per_batch=2))
     dev.preprocess(sc)
     worker = threading.Thread(target=cpu_device)
     dev.start(sc, xpu.FrameState(6, queue, film))
@@ -604,7 +604,7 @@ def test_one_device_many_scenes_and_frames(xpu):
     from phosphorus_mk2_amd import scenes
     a, b, c = scenes.cornell(96, 64), scenes.soup(4000, width=64, height=96), scenes.multi_material_soup(2000, width=64, height=64)
     fresh = {id(s): xpu.render(s, spp=5, seed=3)[0] for s in (a, b, c)}
-    dev = xpu.HipDevice.discover(xpu.Options(samples_per_pixel=5, paths_per_sample=1))[0]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=5, paths_per_sample=1))
     for s in (a, b, c, b, a):
         dev.preprocess(s)
         W, H = s.camera.width, s.camera.height
