@@ -11,26 +11,30 @@ value = rays traced by ALL ranks (closest-hit + non-masked shadow rays, SURVEY Â
 Scene upload and BVH build (xpu_t::preprocess) happen before the timed region: inputs are HBM-resident.
 
 Extra objects on the JSON line (N = 1 only):
+  value_host_film  the same frame timed through the host film sink (the xpu_t boundary's add_tile: 14.7 MB over PCIe per frame),
+               the rate the reference's own start...join bracket would see; `value` keeps the film in HBM.
   roofline     of the dominant kernel, k_trace (closest-hit rays of a step + shadow rays of the previous step in one persistent
-               launch; time = HIP events on the device's own stream around every launch of the timed steps).  Every `frac` is a
-               real fraction of a stated ceiling:
-                 valu          the bound: the node visits and triangle tests the frame needs (counted by the instrumented
-                               build, libphx_hip_count.so, on the same frame) priced at the rate the chip runs k_trace's own
-                               arithmetic with nothing else in the way (scripts/micro/valu_mix.hip, profiles/r02_valu_mix.json)
-                               = minimum ALU time / k_trace time
-                 valu_issue    VALU wave-instructions issued (committed PMC pass) vs 256 CUs x 4 SIMDs x 1 per 2 clocks
-                 vector_l1     vector-L1 lane addresses (PMC) vs the measured 1.7 per clock and CU (scripts/micro/l1_gather.hip)
-                 l2            L1->L2 read requests x 64 B (PMC) vs 34.5 TB/s
+               launch; time = HIP events on the device's own stream around every launch of the timed steps).
+               `frac` is WORK-based (bound "valu"): the node visits and triangle tests the frame needs (counted by the instrumented
+               build, libphx_hip_count.so, on the same frame) priced at the rate the chip runs k_trace's own arithmetic with nothing
+               else in the way (scripts/micro/valu_mix.hip, profiles/r*_valu_mix.json) = minimum ALU time / k_trace time measured
+               in THIS run.  `diagnostics` are counter rates, each taken from ONE committed capture (profiles/r*_<tag>_pmc.json)
+               and divided by the kernel time of THAT capture's --kernel-trace --stats pass (kernel_ms_stats_pass), never by this
+               run's time:
+                 valu_issue    VALU wave-instructions issued vs 256 CUs x 4 SIMDs x 1 per 2 clocks (rewards wasted instructions:
+                               a diagnostic, not the fraction)
+                 vector_l1     vector-L1 lane addresses vs the measured 1.7 per clock and CU (scripts/micro/l1_gather.hip)
+                 l2            L1->L2 read requests x 64 B vs 34.5 TB/s
                  hbm           FETCH_SIZE x 2 + WRITE_SIZE (separate PMC passes, MI355X_MICROARCH.md) vs 8 TB/s; `traffic` = those
                                bytes per launch
-               `algorithmic_ref_layout` keeps SURVEY Â§8(d)'s figure (bytes per ray in the REFERENCE's 288-B node / 384-B packet
-               layout, V_n and V_l from the CPU restatement's counters): a work-normalised rate, not a bound â€” the device's tree
-               is smaller and lives in L2.  `device_layout` = the bytes this kernel's own layout moves per ray.
+               `algorithmic_ref_layout` keeps SURVEY 8(d)'s figure (bytes per ray in the REFERENCE's 288-B node / 384-B packet
+               layout, V_n and V_l from the CPU restatement's counters): a work-normalised rate, not a bound.
   cpu_baseline the CPU restatement (oracle/, kind "port") on this box's host cores: a warm thread pool renders tiles of the same
-               frame (counter RNG) for >= 10 s; thread start-up and per-thread stream construction are outside the clock; rates
-               at 1, 8, 64, the physical cores and all hardware threads are listed.
-  secondary    the same measurement on Soup(1 M) (the north star's target scene) and on the whole BASELINE config-4 frame
-               (Soup(10 M), 3840x2160, 256 spp) on this one GPU.
+               frame (counter RNG) for >= 10 s; thread start-up and per-thread stream construction are outside the clock.
+  secondary    the same measurement on Soup(1 M) (the north star's target scene), on the whole BASELINE config-4 frame
+               (Soup(10 M), 3840x2160, 256 spp) on this one GPU, and on the declared stand-ins for BASELINE configs 3 and 5 (no BMW
+               scene ships with the reference): the 16-recipe multi_material_soup(500 000) at 1920x1080, 256 spp and at 3840x2160,
+               64 of 4096 spp â€” those two carry a roofline of the general-closure shade kernel, k_shade_g.
 """
 import argparse
 import glob
@@ -72,6 +76,7 @@ def parse():
     p.add_argument("--bvh-builder", choices=["auto", "host", "device"], default="auto",
                    help="auto (host binned SAH up to 2 M triangles, device LBVH above), host, device")
     p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
+    p.add_argument("--one-sink", action="store_true", help="do not time the frames a second time through the other film sink (profiling captures: one frame per run)")
     p.add_argument("--host-film", action="store_true", help="N=1: hand the frame to the host film sink (PCIe inside the timed region) instead of a device film")
     return p.parse_args()
 
@@ -161,30 +166,12 @@ def cpu_baseline(scene, args, seconds=None, thread_counts=None):
 
 
 # ---- committed measurements bench.py cannot take itself -------------------------------------------------------
-def workload_tag(triangles, width, height, depth=9):
-    return {(100000, 1280, 720): "100k", (1000000, 1280, 720): "1M", (10000000, 3840, 2160): "c4"}.get((triangles, width, height)) if depth == 9 else None
-
-
-def committed_pmc(args_like):
-    """k_trace's PMC sums of one frame of this workload from the newest committed summary (profiles/r*_<tag>_pmc.json, written by
-    scripts/summarize_profile.py from separate rocprofv3 passes).  bench.py cannot collect PMCs itself; other workloads get None."""
-    tag = workload_tag(args_like.triangles, args_like.width, args_like.height, args_like.depth)
-    if tag is None:
-        return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    e = d["kernels"].get("k_trace")
-    return (e, os.path.relpath(files[-1], ROOT)) if e else (None, None)
-
-
-def committed_traffic(args_like):
-    """HBM bytes per k_trace launch (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) from the newest committed PMC summary"""
-    e, src = committed_pmc(args_like)
-    if e and "hbm_bytes_per_launch_corrected" in e:
-        return e["hbm_bytes_per_launch_corrected"], src
-    return None, None
+def workload_tag(kind, triangles, width, height, depth=9):
+    """name of the committed PMC capture of this workload (profiles/r*_<tag>_pmc.json), None if there is none"""
+    if depth != 9:
+        return None
+    return {("soup", 100000, 1280, 720): "100k", ("soup", 1000000, 1280, 720): "1M", ("soup", 10000000, 3840, 2160): "c4",
+            ("zoo", 500000, 1920, 1080): "zoo", ("zoo", 500000, 3840, 2160): "zoo4k"}.get((kind, triangles, width, height))
 
 
 def committed_valu_peak():
@@ -207,27 +194,68 @@ def count_work(triangles, width, height, spp, builder):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-def roofline(acc, steps, work, pmc, pmc_src, ref_visits, like):
-    """acc: rays and k_trace ms summed over `steps` timed frames; work: count_work() of one frame; pmc: committed PMC entry"""
+def load_capture(tag):
+    """the newest committed capture profiles/r*_<tag>_pmc.json (scripts/summarize_profile.py) -> (dict, relative path)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), key=lambda f: (os.path.getmtime(f), f)) if tag else []
+    if not files:
+        return None, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+def capture_diagnostics(cap, src, kernel, units_in_capture):
+    """counter rates of `kernel` from ONE capture: every count is divided by the kernel's time in that capture's own
+    --kernel-trace --stats pass.  units_in_capture = rays (k_trace) or shaded hits (k_shade*) of the captured command, if known."""
+    e = cap["kernels"].get(kernel)
+    kt = (cap.get("kernel_ms_stats_pass") or {}).get(kernel)
+    if kt is None and kernel == "k_trace" and cap.get("k_trace_launch_ms"):
+        kt = {"launches": len(cap["k_trace_launch_ms"]), "total_ms": sum(cap["k_trace_launch_ms"])}
+    if not e or not kt:
+        return None
+    c, n = e["counters"], e["launches"]
+    t = kt["total_ms"] * 1e-3 * (n / kt["launches"])  # seconds of the n launches the PMC passes summed over
+    D = {"source": src, "kernel_ms_in_capture": kt["total_ms"], "launches_in_capture": kt["launches"], "pmc_launches": n}
+    if "SQ_INSTS_VALU" in c:
+        a = c["SQ_INSTS_VALU"] / t
+        D["valu_issue"] = {"achieved": a / 1e9, "peak": CUS * 4 * CLOCK_HZ / 2 / 1e9, "unit": "G wave-instructions/s", "frac": a / (CUS * 4 * CLOCK_HZ / 2),
+                           "lane_utilisation": e.get("valu_lane_utilisation"), "wave_cycles_waiting_frac": e.get("wave_cycles_waiting_frac")}
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / t
+        D["vector_l1"] = {"achieved": a / 1e9, "peak": L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ / 1e9, "unit": "G lane addresses/s",
+                          "frac": a / (L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ), "l1_hit_rate": e.get("l1_hit_rate"),
+                          "ta_busy_frac": e.get("ta_busy_frac"), "td_busy_frac": e.get("td_busy_frac")}
+    if "TCP_TCC_READ_REQ_sum" in c:
+        a = c["TCP_TCC_READ_REQ_sum"] * 64.0 / t
+        D["l2"] = {"achieved": a / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": a / 1e9 / L2_PEAK_GBS, "l2_hit_rate": e.get("l2_hit_rate")}
+    if "hbm_bytes_per_launch_corrected" in e:
+        a = e["hbm_bytes_per_launch_corrected"] * n / t
+        D["hbm"] = {"achieved": a / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / 1e9 / HBM_PEAK_GBS,
+                    "bytes_per_launch": e["hbm_bytes_per_launch_corrected"], "bytes_per_launch_uncorrected": e.get("hbm_bytes_per_launch_raw")}
+        if units_in_capture:
+            D["hbm"]["bytes_per_unit"] = e["hbm_bytes_per_launch_corrected"] * n / units_in_capture
+    return D
+
+
+def roofline(acc, steps, work, tag, ref_visits):
+    """k_trace.  acc: rays and k_trace ms summed over `steps` timed frames of THIS run; work: count_work() of one frame (instrumented
+    build, same frame); tag: which committed capture holds this workload's counters."""
     nl = max(1, acc["launches"])
-    t_frame = acc["closest_ms"] * 1e-3 / steps          # k_trace seconds per frame (HIP events)
+    t_frame = acc["closest_ms"] * 1e-3 / steps          # k_trace seconds per frame (HIP events, this run)
     t_launch = acc["closest_ms"] * 1e-3 / nl
     rays_c, rays_s = acc["closest"] / steps, acc["shadow"] / steps
     roof = {"kernel": "k_trace", "launches_per_step": nl / steps, "avg_launch_ms": t_launch * 1e3,
             "rays_per_launch": (acc["closest"] + acc["shadow"]) / nl, "kernel_rays_per_s": (rays_c + rays_s) / t_frame,
-            "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "ceilings": {}}
-    C = roof["ceilings"]
+            "bound": "valu", "achieved": None, "peak": None, "unit": "G node-visit equivalents/s", "frac": None, "traffic": None}
     peak, peak_src = committed_valu_peak()
     if work and "error" not in work and peak:
         nv = sum(work[k]["rays"] * (work[k]["node_visits_lds_per_ray"] + work[k]["node_visits_mem_per_ray"]) for k in ("closest", "shadow"))
         tt = sum(work[k]["rays"] * work[k]["tri_tests_per_ray"] for k in ("closest", "shadow"))
         t_min = nv / peak["node_tests_per_s"] + tt / peak["tri_tests_per_s"]
-        C["valu"] = {"achieved": nv / t_frame / 1e9, "peak": nv / t_min / 1e9, "unit": "G node-visit equivalents/s", "frac": t_min / t_frame,
-                     "node_visits_per_frame": nv, "tri_tests_per_frame": tt, "min_alu_ms_per_frame": t_min * 1e3,
-                     "peak_node_tests_per_s": peak["node_tests_per_s"], "peak_tri_tests_per_s": peak["tri_tests_per_s"], "peak_source": peak_src,
-                     "lanes_per_node_block": work["wave"]["lanes_per_node_block"], "lanes_per_tri_block": work["wave"]["lanes_per_tri_block"],
-                     "what": "node visits + triangle tests of this frame (instrumented build) priced at the chip's rate for k_trace's own "
-                             "arithmetic alone (all 64 lanes active, operands in registers) = minimum ALU time / k_trace time"}
+        roof.update({"achieved": nv / t_frame / 1e9, "peak": nv / t_min / 1e9, "frac": t_min / t_frame})
+        roof["work"] = {"node_visits_per_frame": nv, "tri_tests_per_frame": tt, "min_alu_ms_per_frame": t_min * 1e3, "k_trace_ms_per_frame": t_frame * 1e3,
+                        "peak_node_tests_per_s": peak["node_tests_per_s"], "peak_tri_tests_per_s": peak["tri_tests_per_s"], "peak_source": peak_src,
+                        "lanes_per_node_block": work["wave"]["lanes_per_node_block"], "lanes_per_tri_block": work["wave"]["lanes_per_tri_block"],
+                        "what": "node visits + triangle tests of this frame (instrumented build, this run) priced at the chip's rate for k_trace's own "
+                                "arithmetic alone (all 64 lanes active, operands in registers) = minimum ALU time / k_trace time of this run"}
         # bytes this kernel's own layout moves per ray: 64-B nodelets through the L1 (LDS-staged ones are free), 48 B of a triangle
         # record, ray in (32 B closest, 48 B shadow incl. its beta*Li), result out (16 B hit record; 32 B radiance read-modify-write)
         dl = {}
@@ -238,29 +266,13 @@ def roofline(acc, steps, work, pmc, pmc_src, ref_visits, like):
                                  "visits_per_ray": {k: {x: work[k][x] for x in ("node_visits_lds_per_ray", "node_visits_mem_per_ray", "tri_tests_per_ray")} for k in ("closest", "shadow")}}
     elif work and "error" in work:
         roof["instrumented_pass_error"] = work["error"]
-    if pmc:
-        c = pmc["counters"]; n = pmc["launches"]
-        scale = nl / steps / n  # PMC sums are over one frame of n launches
-        if "SQ_INSTS_VALU" in c:
-            a = c["SQ_INSTS_VALU"] * scale / t_frame
-            C["valu_issue"] = {"achieved": a / 1e9, "peak": CUS * 4 * CLOCK_HZ / 2 / 1e9, "unit": "G wave-instructions/s", "frac": a / (CUS * 4 * CLOCK_HZ / 2),
-                               "lane_utilisation": pmc.get("valu_lane_utilisation")}
-        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
-            a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] * scale / t_frame
-            C["vector_l1"] = {"achieved": a / 1e9, "peak": L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ / 1e9, "unit": "G lane addresses/s",
-                              "frac": a / (L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ), "per_ray": c["TCP_TOTAL_CACHE_ACCESSES_sum"] * scale / (rays_c + rays_s)}
-        if "TCP_TCC_READ_REQ_sum" in c:
-            a = c["TCP_TCC_READ_REQ_sum"] * scale * 64.0 / t_frame
-            C["l2"] = {"achieved": a / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": a / 1e9 / L2_PEAK_GBS, "l2_hit_rate": pmc.get("l2_hit_rate")}
-        if "hbm_bytes_per_launch_corrected" in pmc:
-            roof["traffic"] = pmc["hbm_bytes_per_launch_corrected"]
-            a = pmc["hbm_bytes_per_launch_corrected"] / t_launch
-            C["hbm"] = {"achieved": a / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / 1e9 / HBM_PEAK_GBS,
-                        "bytes_per_ray": pmc["hbm_bytes_per_launch_corrected"] * n / (rays_c + rays_s)}
-        roof["pmc_source"] = pmc_src
-    if C:
-        b = max(C, key=lambda k: C[k]["frac"])
-        roof.update({"bound": b, "achieved": C[b]["achieved"], "peak": C[b]["peak"], "unit": C[b]["unit"], "frac": C[b]["frac"]})
+    cap, src = load_capture(tag)
+    if cap:
+        D = capture_diagnostics(cap, src, "k_trace", rays_c + rays_s)  # the captures render this same frame once
+        if D:
+            roof["diagnostics"] = D
+            if "hbm" in D:
+                roof["traffic"] = D["hbm"]["bytes_per_launch"]
     if ref_visits:
         (vn, vl), (vns, vls) = ref_visits["closest"], ref_visits["shadow"]
         b_ray, b_shadow = 56.0 + vn * 288.0 + vl * 384.0, 36.0 + vns * 288.0 + vls * 384.0
@@ -272,17 +284,68 @@ def roofline(acc, steps, work, pmc, pmc_src, ref_visits, like):
     return roof
 
 
-def run_workload(xpu, scenes, triangles, width, height, spp, depth, seed, builder, steps, warmup, samples_in_flight=0):
-    """one device, one scene, `steps` timed frames on one GPU -> (value Mrays/s, ms per step, acc, last stats, preprocess s)"""
-    scene = scenes.soup(triangles, seed=1234, width=width, height=height)
+# algorithmic bytes per shaded queue entry in the device's layout: in â€” hit 16, ray 32, path state 16,
+# triangle record 64 (one 64-B element of the pool); out â€” next ray 32 + path state 16 for a survivor, 48 for an NEE ray
+SHADE_BYTES_IN, SHADE_BYTES_SURVIVOR, SHADE_BYTES_NEE = 16 + 32 + 16 + 64, 32 + 16, 48
+
+
+def shade_roofline(acc, steps, st, tag):
+    """the shade/NEE/integrate kernel (k_shade_g for general closures): HBM-stream roofline.  One launch shades every entry of a
+    ray queue: algorithmic bytes = entries x (hit + ray + state + triangle record) + survivors x (next ray + state) + NEE rays x 48,
+    all counted by the device in this run."""
+    nl = max(1, acc["shade_launches"])
+    t = acc["shade_kernel_ms"] * 1e-3
+    entries, nee = acc["closest"], acc["shadow"]
+    survivors = max(0, acc["closest"] - acc["camera"])  # every closest-hit ray after the camera rays is a survivor of a shade launch
+    alg = entries * SHADE_BYTES_IN + survivors * SHADE_BYTES_SURVIVOR + nee * SHADE_BYTES_NEE
+    kernel = "k_shade_g" if st.get("shade_general") else "k_shade"
+    roof = {"kernel": kernel, "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "launches_per_step": nl / steps, "avg_launch_ms": t * 1e3 / nl, "entries_per_launch": entries / nl,
+            "algorithmic_bytes_per_launch": alg / nl, "algorithmic_bytes_per_entry": alg / max(1, entries),
+            "shaded_entries_per_s": entries / t}
+    cap, src = load_capture(tag)
+    if cap:
+        D = capture_diagnostics(cap, src, kernel, None)
+        if D:
+            roof["diagnostics"] = D
+            if "hbm" in D:
+                roof["traffic"] = D["hbm"]["bytes_per_launch"]
+    res = os.path.join(ROOT, "profiles")
+    files = sorted(glob.glob(os.path.join(res, "r*_kernel_resources.txt")))
+    if files:
+        for line in open(files[-1]):
+            if line.startswith(kernel + "<") or line.startswith(kernel + " "):
+                f = line.split()
+                roof.setdefault("resources", {"source": os.path.relpath(files[-1], ROOT), "variants": []})["variants"].append(
+                    {"kernel": " ".join(f[:-6]), "vgprs": int(f[-6]), "scratch_bytes": int(f[-3]), "waves_per_simd": int(f[-1])})
+    return roof
+
+
+def new_acc():
+    return {"closest": 0, "shadow": 0, "camera": 0, "closest_ms": 0.0, "shade_ms": 0.0, "shade_kernel_ms": 0.0, "shade_launches": 0, "launches": 0, "frame_ms": 0.0}
+
+
+def add_stats(acc, st):
+    acc["closest"] += st["rays_closest"]; acc["shadow"] += st["rays_shadow"]; acc["camera"] += st["camera_samples"]
+    acc["closest_ms"] += st["closest_ms"]; acc["shade_ms"] += st["shade_ms"]; acc["launches"] += st["trace_launches"]
+    acc["shade_kernel_ms"] += st["shade_kernel_ms"]; acc["shade_launches"] += st["shade_launches"]; acc["frame_ms"] += st["frame_ms"]
+
+
+def make_scene(scenes, kind, triangles, width, height):
+    return scenes.multi_material_soup(triangles, seed=1234, width=width, height=height) if kind == "zoo" else scenes.soup(triangles, seed=1234, width=width, height=height)
+
+
+def run_workload(xpu, scenes, kind, triangles, width, height, spp, depth, seed, builder, steps, warmup, samples_in_flight=0):
+    """one device, one scene, `steps` timed frames with the film in HBM, then `steps` more through the host film sink
+    -> (value Mrays/s, ms per step, acc, last stats, preprocess s, scene, film, value through the host film)"""
+    scene = make_scene(scenes, kind, triangles, width, height)
     import torch
     dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=depth, samples_in_flight=samples_in_flight,
                                          bvh_builder=builder, device_ordinal=torch.cuda.current_device()))
     t0 = time.time(); dev.preprocess(scene); pre = time.time() - t0
     tiles = xpu.Tiles.make(width, height, 32)
-    import torch  # device memory for the film, which stays in HBM inside the timed region (as in main())
     film_dev = torch.zeros((height, width, 4), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-    acc = {"closest": 0, "shadow": 0, "closest_ms": 0.0, "shade_ms": 0.0, "launches": 0, "frame_ms": 0.0}
+    acc = new_acc()
     st = None
     for i in range(warmup + steps):
         if i == warmup:
@@ -292,32 +355,46 @@ def run_workload(xpu, scenes, triangles, width, height, spp, depth, seed, builde
         dev.start(scene, xpu.FrameState(seed, tiles, None, device_film_ptr=film_dev.data_ptr())); dev.join()
         st = dev.stats()
         if i >= warmup:
-            acc["closest"] += st["rays_closest"]; acc["shadow"] += st["rays_shadow"]; acc["closest_ms"] += st["closest_ms"]
-            acc["shade_ms"] += st["shade_ms"]; acc["launches"] += st["trace_launches"]; acc["frame_ms"] += st["frame_ms"]
+            add_stats(acc, st)
     elapsed = time.perf_counter() - t0
     film = film_dev.cpu().numpy()
     del film_dev
+    host = xpu.Film(width, height, 4)
+    rays_h = 0
+    for i in range(1 + steps):  # one warm-up frame sizes the pinned staging buffer
+        if i == 1:
+            t0 = time.perf_counter()
+        tiles.reset()
+        dev.start(scene, xpu.FrameState(seed, tiles, host, native_sink=True)); dev.join()
+        if i >= 1:
+            h = dev.stats(); rays_h += h["rays_closest"] + h["rays_shadow"]
+    value_host = rays_h / (time.perf_counter() - t0) / 1e6
     dev.close()
-    return (acc["closest"] + acc["shadow"]) / elapsed / 1e6, elapsed * 1e3 / steps, acc, st, pre, scene, film
+    return (acc["closest"] + acc["shadow"]) / elapsed / 1e6, elapsed * 1e3 / steps, acc, st, pre, scene, film, value_host
 
 
-def secondary_record(xpu, scenes, name, triangles, width, height, spp, args, cpu_seconds):
+def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, args, cpu_seconds):
     like = argparse.Namespace(triangles=triangles, width=width, height=height, depth=args.depth, spp=spp, seed=args.seed, cpu_spp=args.cpu_spp,
                               cpu_seconds=cpu_seconds)
-    value, ms, acc, st, pre, scene, film = run_workload(xpu, scenes, triangles, width, height, spp, args.depth, args.seed, "auto", steps=2, warmup=1)
-    rec = {"workload": name, "value": value, "unit": "Mrays/s", "ms_per_step": ms, "steps": 2, "rays_per_step": (acc["closest"] + acc["shadow"]) / 2,
+    value, ms, acc, st, pre, scene, film, value_host = run_workload(xpu, scenes, kind, triangles, width, height, spp, args.depth, args.seed, "auto", steps=2, warmup=1)
+    rec = {"workload": name, "value": value, "value_host_film": value_host, "unit": "Mrays/s", "ms_per_step": ms, "steps": 2, "rays_per_step": (acc["closest"] + acc["shadow"]) / 2,
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
-           "kernel_ms_per_step": {"trace": acc["closest_ms"] / 2, "shade_gen_film": acc["shade_ms"] / 2}, "film_finite": bool(np.isfinite(film).all())}
+           "kernel_ms_per_step": {"trace": acc["closest_ms"] / 2, "shade": acc["shade_kernel_ms"] / 2, "begin_pass_film": (acc["shade_ms"] - acc["shade_kernel_ms"]) / 2},
+           "film_finite": bool(np.isfinite(film).all())}
+    tag = workload_tag(kind, triangles, width, height, args.depth)
+    if kind == "zoo":
+        rec["roofline"] = shade_roofline(acc, 2, st, tag)
+        rec["roofline_k_trace"] = roofline(acc, 2, None, tag, None)
+        return rec
     work = count_work(triangles, width, height, spp, "auto")
-    pmc, src = committed_pmc(like)
     ref_visits = None
     if cpu_seconds > 0:
         logical, _, share = host_cpus()
         base, ref_visits = cpu_baseline(scene, like, seconds=cpu_seconds, thread_counts={1: 0.2, max(1, min(logical, int(round(share)))): 1.0, min(64, logical): 0.5})
         rec["cpu_baseline"] = base
         rec["gpu_over_cpu"] = value / base["value"]
-    rec["roofline"] = roofline(acc, 2, work, pmc, src, ref_visits, like)
+    rec["roofline"] = roofline(acc, 2, work, tag, ref_visits)
     return rec
 
 
@@ -384,14 +461,34 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    acc = {"closest": 0, "shadow": 0, "closest_ms": 0.0, "shade_ms": 0.0, "launches": 0, "frame_ms": 0.0}
+    acc = new_acc()
     for _ in range(args.steps):
         st = step()
-        acc["closest"] += st["rays_closest"]; acc["shadow"] += st["rays_shadow"]
-        acc["closest_ms"] += st["closest_ms"]; acc["shade_ms"] += st["shade_ms"]
-        acc["launches"] += st["trace_launches"]; acc["frame_ms"] += st["frame_ms"]
+        add_stats(acc, st)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the same frames once more through the OTHER film sink (N = 1): `value` keeps the film in HBM, `value_host_film` hands every
+    # frame to a host frame buffer as xpu_t's add_tile does (the reference's own start...join bracket, src/core.cpp:158-177)
+    value_other = None
+    if not use_dist and not args.one_sink:
+        other_dev = film_dev is None
+        if other_dev:
+            film_other = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
+        else:
+            film_other = xpu.Film(W, H, 4)
+        rays_o = 0
+        for i in range(1 + args.steps):
+            if i == 1:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            tiles.reset()
+            if other_dev:
+                dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_other.data_ptr()))
+            else:
+                dev.start(scene, xpu.FrameState(args.seed, tiles, film_other, native_sink=True))
+            dev.join()
+            if i >= 1:
+                so = dev.stats(); rays_o += so["rays_closest"] + so["rays_shadow"]
+        value_other = rays_o / (time.perf_counter() - t1) / 1e6
     rays_local = acc["closest"] + acc["shadow"]
     if use_dist:
         elapsed = pdist.max_over_ranks(elapsed, "cuda")
@@ -407,6 +504,8 @@ def main():
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "value_film": "host (PCIe inside the timed region, --host-film)" if film_dev is None else "hbm (device film: nothing crosses PCIe inside a step)",
+            "value_host_film": value if film_dev is None else value_other, "value_hbm_film": value_other if film_dev is None else value,
             "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "
                                    "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
                        "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0" if use_dist else "none",
@@ -422,23 +521,27 @@ def main():
             base, ref_visits = cpu_baseline(scene, args)
             out["cpu_baseline"] = base
             out["config"]["gpu_over_cpu"] = value / base["value"]
-            pmc, src = committed_pmc(args)
-            out["roofline"] = roofline(acc, args.steps, work, pmc, src, ref_visits, args)
+            out["roofline"] = roofline(acc, args.steps, work, workload_tag("soup", args.triangles, W, H, args.depth), ref_visits)
             if not args.no_secondary and (args.triangles, W, H, args.spp) == (100000, 1280, 720, 256):
                 sec = []
                 sec.append(secondary_record(xpu, scenes, "Soup(1000000, seed 1234) 1280x720 256 spp depth 9 (north star's target scene)",
-                                            1000000, 1280, 720, 256, args, cpu_seconds=args.cpu_seconds))
+                                            "soup", 1000000, 1280, 720, 256, args, cpu_seconds=args.cpu_seconds))
                 sec.append(secondary_record(xpu, scenes, "Soup(10000000, seed 1234) 3840x2160 256 spp depth 9: the whole BASELINE config-4 frame on ONE GPU",
-                                            10000000, 3840, 2160, 256, args, cpu_seconds=0))
+                                            "soup", 10000000, 3840, 2160, 256, args, cpu_seconds=0))
+                sec.append(secondary_record(xpu, scenes, "stand-in for BASELINE config 3 (no BMW scene ships with the reference): multi_material_soup(500000), 16 closure "
+                                            "recipes over all 7 lobe models, 1920x1080, 256 of 1024 spp, depth 9, whole frame on one GPU",
+                                            "zoo", 500000, 1920, 1080, 256, args, cpu_seconds=0))
+                sec.append(secondary_record(xpu, scenes, "stand-in for BASELINE config 5: the same 16-recipe scene at 3840x2160, 64 of 4096 spp, depth 9, whole frame on one GPU "
+                                            "(the shading-bound regime: k_shade_g)",
+                                            "zoo", 500000, 3840, 2160, 64, args, cpu_seconds=0))
                 out["secondary"] = sec
         else:
             out["cpu_baseline"] = None
-            pmc, src = committed_pmc(args) if world == 1 else (None, None)
-            out["roofline"] = roofline(acc, args.steps, None, pmc, src, None, args) if world == 1 else {
+            out["roofline"] = roofline(acc, args.steps, None, workload_tag("soup", args.triangles, W, H, args.depth), None) if world == 1 else {
                 "bound": None, "kernel": "k_trace", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "note": "roofline and cpu_baseline are reported at N = 1"}
-        out["config"]["kernel_ms_per_step"] = {"trace": acc["closest_ms"] / args.steps, "shade_gen_film": acc["shade_ms"] / args.steps,
-                                               "frame": acc["frame_ms"] / args.steps}
+        out["config"]["kernel_ms_per_step"] = {"trace": acc["closest_ms"] / args.steps, "shade": acc["shade_kernel_ms"] / args.steps,
+                                               "begin_pass_film": (acc["shade_ms"] - acc["shade_kernel_ms"]) / args.steps, "frame": acc["frame_ms"] / args.steps}
         print(json.dumps(out))
     else:
         dev.close()

@@ -220,6 +220,9 @@ typedef struct phx_stats {
   double   bvh_cost_model;     /* modelled traversal cost of the tree in use (the optimal collapse's objective; area units) */
   uint64_t trace_lds_levels;   /* ... of which this many live in LDS (deep trees: the rest spills to HBM) */
   uint64_t bvh_built_on_device; /* 1: the tree in use was built on the device */
+  double   shade_kernel_ms;    /* of shade_ms: the shade/NEE/integrate launches alone (k_shade or k_shade_g), HIP events */
+  uint64_t shade_launches;     /* how many of them */
+  uint64_t shade_general;      /* 1: the scene has non-Lambert closures and runs k_shade_g; 0: k_shade (Lambert only) */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

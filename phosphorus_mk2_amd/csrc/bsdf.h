@@ -83,7 +83,7 @@ PHX_HD float sin_phi(const v3& v) { float s = sin_theta(v); return (s == 0.0f) ?
 PHX_HD void cosine_weighted(float u1, float u2, v3& out, float& pdf) {  // math/sampling.hpp:23-36
   const float r = sqrtf(u1);
   const float theta = (float)(2 * kPiD * (double)u2);
-  float s, c; sincosf_(theta, &s, &c);
+  const sincosf_t sc = sincosf_(theta); const float s = sc.s, c = sc.c;
   out = v3(r * c, sqrtf(fmaxf(0.0f, 1.0f - u1)), r * s);
   pdf = out.y * (float)(1.0 / kPiD);
 }
@@ -166,7 +166,7 @@ PHX_HD void ggx_sample_slope(float cos_theta, float& slope_x, float& slope_y, fl
   if ((double)cos_theta > .9999) {
     const float r = sqrtf(u / (1 - u));
     const float phi = (float)(6.28318530718 * (double)v);
-    float s, c; sincosf_(phi, &s, &c);
+    const sincosf_t sc = sincosf_(phi); const float s = sc.s, c = sc.c;
     slope_x = r * c; slope_y = r * s;
     return;
   }

@@ -107,7 +107,7 @@ struct phx_device {
   uint64_t paths_in_flight = 0;
   double bvh_cost_model = 0; uint32_t bvh_built_on_device = 0;
   std::vector<hipEvent_t> events; size_t events_used = 0;
-  std::vector<std::pair<size_t, int>> timed;  // (event index of start, kind 0 closest / 1 shadow / 2 other)
+  std::vector<std::pair<size_t, int>> timed;  // (event index of start, kind 0 k_trace / 2 begin-pass, film / 3 shade)
 
   ~phx_device() {
     if (driver.joinable()) driver.join();
@@ -468,6 +468,7 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   out->trace_waves_per_cu = (uint64_t)d->plan.wg_per_cu * (d->plan.block / 64u); out->bvh_depth = d->scene.stack_levels;
   out->paths_in_flight = d->paths_in_flight;
   out->bvh_cost_model = d->bvh_cost_model; out->bvh_built_on_device = d->bvh_built_on_device;
+  out->shade_general = d->scene.diffuse_only ? 0 : 1;
   return PHX_OK;
 }
 
@@ -659,6 +660,7 @@ int phx_device::run_frame() {
     HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));
     if (te.second == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
     else stats.shade_ms += ms;
+    if (te.second == 3) { stats.shade_kernel_ms += ms; stats.shade_launches++; }
   }
   stats.trace_ms = stats.closest_ms + stats.shadow_ms;
   stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -754,7 +756,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
       // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
       const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
       if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap, bounce == 0, s0); }))) return rc;
-      if ((rc = timed_launch(2, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
+      if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
       q ^= 1;
     }
     if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap, 0, s0); }))) return rc;

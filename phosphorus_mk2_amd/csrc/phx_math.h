@@ -14,9 +14,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PHX_HD __host__ __device__ __forceinline__
-// The binary64 kernels below are real functions on the device, not inlined into every lobe model that uses them: inlined, their
-// 40 polynomial coefficients (register pairs: a 64-bit literal cannot be an instruction operand) were hoisted in front of the lobe
-// loops of bsdf_f / bsdf_sample and stayed alive across them - 46 VGPRs of constants in a kernel capped at 128.
+// sincosf_ / expf_ / logf_ / powf_ are real (leaf) functions on the device, not inlined into every lobe model that uses them:
+// inlined, the 40 coefficients of their binary64 kernels (register pairs: a 64-bit literal cannot be an instruction operand) were
+// hoisted in front of the lobe loops of bsdf_f / bsdf_sample and stayed alive across them - 46 VGPRs of constants in a kernel
+// capped at 128.  The binary64 kernels themselves are inlined INTO those four, so no call is nested and no stack is needed; the
+// arguments and results are fp32 (two or three registers per call).
 #define PHX_HD_CALL inline __host__ __device__ __attribute__((noinline))
 #else
 #define PHX_HD inline
@@ -73,7 +75,7 @@ PHX_HD double u64_as_double(uint64_t u) { union { uint64_t u; double d; } c; c.u
 PHX_HD uint64_t double_as_u64(double d) { union { uint64_t u; double d; } c; c.d = d; return c.u; }
 
 struct sincos_t { double s, c; };
-PHX_HD_CALL sincos_t sincos_d(double x) {  // by value: out-pointers of a real function would be stack slots
+PHX_HD sincos_t sincos_d(double x) {
   const double two_over_pi = 6.36619772367581382433e-01;
   const double pio2_hi = 1.57079632679489655800e+00;
   const double pio2_lo = 6.12323399573676603587e-17;
@@ -97,7 +99,7 @@ PHX_HD_CALL sincos_t sincos_d(double x) {  // by value: out-pointers of a real f
   else { ss = -cr; cc = sr; }
   return sincos_t{ss, cc};
 }
-PHX_HD_CALL double exp_d(double x) {
+PHX_HD double exp_d(double x) {
   const double inv_ln2 = 1.44269504088896338700e+00;
   const double ln2_hi = 6.93147180369123816490e-01;
   const double ln2_lo = 1.90821492927058770002e-10;
@@ -126,7 +128,7 @@ PHX_HD_CALL double exp_d(double x) {
   double s2 = u64_as_double((uint64_t)(1023 + k2) << 52);
   return p * s1 * s2;
 }
-PHX_HD_CALL double log_d(double x) {
+PHX_HD double log_d(double x) {
   const double ln2_hi = 6.93147180369123816490e-01;
   const double ln2_lo = 1.90821492927058770002e-10;
   uint64_t u = double_as_u64(x);
@@ -155,20 +157,21 @@ PHX_HD_CALL double log_d(double x) {
   double ed = (double)e;
   return fma(ed, ln2_hi, fma(ed, ln2_lo, lm));
 }
-PHX_HD void sincosf_(float x, float* s, float* c) { const sincos_t r = sincos_d((double)x); *s = (float)r.s; *c = (float)r.c; }
-PHX_HD float expf_(float x) {
+struct sincosf_t { float s, c; };
+PHX_HD_CALL sincosf_t sincosf_(float x) { const sincos_t r = sincos_d((double)x); return sincosf_t{(float)r.s, (float)r.c}; }  // by value: out-pointers would be stack slots
+PHX_HD_CALL float expf_(float x) {
   if (x != x) return x;
   if (x > 89.0f) return INFINITY;
   if (x < -104.0f) return 0.0f;
   return (float)exp_d((double)x);
 }
-PHX_HD float logf_(float x) {
+PHX_HD_CALL float logf_(float x) {
   if (x != x || x < 0.0f) return NAN;
   if (x == 0.0f) return -INFINITY;
   if (isinf(x)) return x;
   return (float)log_d((double)x);
 }
-PHX_HD float powf_(float x, float y) {
+PHX_HD_CALL float powf_(float x, float y) {
   if (y == 0.0f) return 1.0f;
   if (x != x || y != y) return NAN;
   if (x == 1.0f) return 1.0f;

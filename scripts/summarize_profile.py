@@ -46,7 +46,7 @@ for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")) + gl
             launches[k].add((os.path.dirname(f), r["Dispatch_Id"]))
         if k == "k_trace":
             per_launch[order[int(r["Dispatch_Id"])]][r["Counter_Name"]].append((os.path.dirname(f), float(r["Counter_Value"])))
-out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+out = {"command": os.environ.get("PROFILE_COMMAND", "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --one-sink " + os.environ.get("BENCH_ARGS", "") + " (scripts/profile_gpu.sh)"),
        "kernels": {}}
 for (k, c), ps in passes.items():
     agg[k][c] /= len(ps)
@@ -96,8 +96,18 @@ out["k_trace_per_launch"] = pl
 # launch durations from the kernel trace of the --stats pass, in dispatch order
 kt = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
 if kt:
-    rows = [r for r in csv.DictReader(open(kt[0])) if kname(r["Kernel_Name"]) == "k_trace"]
+    allrows = list(csv.DictReader(open(kt[0])))
+    rows = [r for r in allrows if kname(r["Kernel_Name"]) == "k_trace"]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     out["k_trace_launch_ms"] = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    # every kernel's time in the --kernel-trace --stats pass of this capture: the duration the PMC sums above are divided by
+    # (bench.py: a counter is never combined with the time of another run)
+    km = collections.defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "launch_ms": []})
+    for r in sorted(allrows, key=lambda r: int(r["Dispatch_Id"])):
+        k = kname(r["Kernel_Name"])
+        if k.startswith("k_"):
+            ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            km[k]["launches"] += 1; km[k]["total_ms"] += ms; km[k]["launch_ms"].append(round(ms, 4))
+    out["kernel_ms_stats_pass"] = km
 json.dump(out, open(os.path.join(dst, f"{name}_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {x: v for x, v in e.items() if x != "counters"} for k, e in out["kernels"].items()}, indent=1))

@@ -26,35 +26,53 @@ def test_cpu_baseline_object_has_the_contract_keys():
 
 def test_committed_measurements_come_from_the_newest_profile_of_this_workload():
     import bench
-    a = argparse.Namespace(triangles=100000, width=1280, height=720, depth=9)
-    traffic, src = bench.committed_traffic(a)
-    assert traffic and traffic > 1e9 and src.startswith("profiles/r") and os.path.exists(os.path.join(ROOT, src))
-    a.triangles = 12345
-    assert bench.committed_traffic(a) == (None, None)  # another workload: no PMC figure is claimed
+    cap, src = bench.load_capture(bench.workload_tag("soup", 100000, 1280, 720, 9))
+    assert cap and src.startswith("profiles/r") and os.path.exists(os.path.join(ROOT, src))
+    assert cap["kernels"]["k_trace"]["hbm_bytes_per_launch_corrected"] > 1e9
+    assert bench.workload_tag("soup", 12345, 1280, 720, 9) is None and bench.load_capture(None) == (None, None)  # another workload: no PMC figure is claimed
     peak, psrc = bench.committed_valu_peak()
     assert peak["node_tests_per_s"] > 1e10 and peak["tri_tests_per_s"] > peak["node_tests_per_s"] and os.path.exists(os.path.join(ROOT, psrc))
 
 
-def test_roofline_fractions_are_fractions():
-    """the roofline object from synthetic inputs: every ceiling carries achieved / peak / frac with frac = achieved / peak <= 1 for
-    physically possible inputs, and `bound` names the highest one"""
+def test_roofline_fraction_is_work_based_and_diagnostics_use_their_own_capture():
+    """the k_trace roofline from synthetic inputs: `frac` is the work-based VALU fraction (minimum ALU time of the counted work over
+    THIS run's kernel time); every diagnostic is a counter of one committed capture over the kernel time OF THAT CAPTURE, so it
+    does not move when this run's time does"""
     import bench
-    acc = {"closest": 441_000_000, "shadow": 123_000_000, "closest_ms": 73.0, "shade_ms": 16.0, "launches": 10, "frame_ms": 90.0}
     work = {k: {"rays": r, "node_visits_lds_per_ray": 5.3, "node_visits_mem_per_ray": 9.0, "tri_tests_per_ray": 5.5} for k, r in (("closest", 441_000_000), ("shadow", 123_000_000))}
     work["wave"] = {"lanes_per_node_block": 52.0, "lanes_per_tri_block": 22.0}
-    a = argparse.Namespace(triangles=100000, width=1280, height=720, depth=9)
-    pmc, src = bench.committed_pmc(a)
-    roof = bench.roofline(acc, 1, work, pmc, src, {"closest": (14.4, 7.2), "shadow": (13.1, 6.5)}, a)
-    assert roof["bound"] in roof["ceilings"] and roof["frac"] == max(c["frac"] for c in roof["ceilings"].values())
-    for name, c in roof["ceilings"].items():
-        assert 0 < c["frac"] <= 1.0, name
-        assert abs(c["frac"] - c["achieved"] / c["peak"]) < 1e-9, name
-    assert roof["traffic"] > 1e9 and "GBps" in roof["algorithmic_ref_layout"] and roof["device_layout"]["bytes_per_ray"]["closest"] > 48
+    roofs = []
+    for ms in (73.0, 146.0):
+        acc = bench.new_acc()
+        acc.update({"closest": 441_000_000, "shadow": 123_000_000, "camera": 235_929_600, "closest_ms": ms, "shade_ms": 16.0, "launches": 10, "frame_ms": 90.0})
+        roofs.append(bench.roofline(acc, 1, work, "100k", {"closest": (14.4, 7.2), "shadow": (13.1, 6.5)}))
+    a, b = roofs
+    assert a["bound"] == "valu" and 0 < a["frac"] <= 1 and abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-9
+    assert abs(a["frac"] - a["work"]["min_alu_ms_per_frame"] / 73.0) < 1e-9 and abs(b["frac"] - a["frac"] / 2) < 1e-9
+    D = a["diagnostics"]
+    assert D["source"].startswith("profiles/r") and D["kernel_ms_in_capture"] > 0
+    for name in ("valu_issue", "vector_l1", "l2", "hbm"):
+        assert 0 < D[name]["frac"] <= 1.0 and abs(D[name]["frac"] - D[name]["achieved"] / D[name]["peak"]) < 1e-9, name
+        assert D[name] == b["diagnostics"][name], name
+    cap = __import__("json").load(open(os.path.join(ROOT, D["source"])))
+    k = cap["kernels"]["k_trace"]
+    t = D["kernel_ms_in_capture"] * 1e-3
+    assert abs(D["valu_issue"]["achieved"] * 1e9 - k["counters"]["SQ_INSTS_VALU"] / t) < 1e-6 * k["counters"]["SQ_INSTS_VALU"] / t
+    assert a["traffic"] == k["hbm_bytes_per_launch_corrected"] and "GBps" in a["algorithmic_ref_layout"] and a["device_layout"]["bytes_per_ray"]["closest"] > 48
+
+
+def test_shade_roofline_counts_algorithmic_bytes_per_entry():
+    import bench
+    acc = bench.new_acc()
+    acc.update({"closest": 600_000_000, "shadow": 400_000_000, "camera": 500_000_000, "shade_kernel_ms": 40.0, "shade_launches": 18})
+    r = bench.shade_roofline(acc, 1, {"shade_general": 1}, None)
+    alg = 600e6 * bench.SHADE_BYTES_IN + 100e6 * bench.SHADE_BYTES_SURVIVOR + 400e6 * bench.SHADE_BYTES_NEE
+    assert r["kernel"] == "k_shade_g" and r["bound"] == "hbm" and abs(r["achieved"] - alg / 0.040 / 1e9) < 1e-6 and 0 < r["frac"] <= 1
 
 
 def test_newest_committed_bench_record_keeps_the_contract():
     """the newest profiles/r*_bench_full.json (written by `python bench.py` on an MI355X) carries every key of the bench contract,
-    fractions that are fractions, and the two secondary records"""
+    fractions that are fractions, and the secondary records"""
     import glob, json
     recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_full.json")))
     assert recs
@@ -69,9 +87,15 @@ def test_newest_committed_bench_record_keeps_the_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["traffic"] > 1e9
-    assert all(0 < c["frac"] <= 1 for c in rf["ceilings"].values()) and rf["bound"] in rf["ceilings"]
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
-    assert len(d["secondary"]) == 2 and all(s["film_finite"] and 0 < s["roofline"]["frac"] <= 1 for s in d["secondary"])
+    assert all(s["film_finite"] and 0 < s["roofline"]["frac"] <= 1 for s in d["secondary"])
+    if os.path.basename(recs[-1]) >= "r03":  # round 3 on: work-based fraction, both film sinks, the config 3 / 5 stand-ins
+        assert rf["bound"] == "valu" and abs(rf["frac"] - rf["work"]["min_alu_ms_per_frame"] / rf["work"]["k_trace_ms_per_frame"]) < 1e-9
+        assert all(0 < rf["diagnostics"][k]["frac"] <= 1 for k in ("valu_issue", "vector_l1", "l2", "hbm"))
+        assert d["value_hbm_film"] == d["value"] and 0 < d["value_host_film"] < 1.05 * d["value"]
+        assert len(d["secondary"]) == 4 and [s["roofline"]["kernel"] for s in d["secondary"]] == ["k_trace", "k_trace", "k_shade_g", "k_shade_g"]
+    else:
+        assert all(0 < c["frac"] <= 1 for c in rf["ceilings"].values()) and rf["bound"] in rf["ceilings"] and len(d["secondary"]) == 2

@@ -382,7 +382,7 @@ def test_plain_c_host_renders_the_same_film(xpu, orc, builder, ndev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "render_room")
     if not os.path.exists(exe):
-        subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True)
+        subprocess.run(["make", "-B", "-C", os.path.join(root, "examples")], check=True)  # -B: a stale binary built against an older header may have travelled with the snapshot
     out = str(tmp_path / "room.f32")
     # ndev > 1: the C host makes that many devices (ordinal i % GPUs of the box), starts them all on ONE queue and ONE film
     r = subprocess.run([exe, out, f"{builder}-bvh"] + ([str(ndev)] if ndev > 1 else []), capture_output=True, text=True, timeout=120)
