@@ -713,6 +713,7 @@ void orc_int_from_float(uint32_t n, const float* x, int32_t* out) {  // _mm256_c
 }
 uint64_t orc_bscf(uint64_t v, uint64_t* rest) { uint64_t x = v; uint64_t i = bscf(x); *rest = x; return i; }
 void orc_radians(uint32_t n, const float* a, float* out) { for (uint32_t i = 0; i < n; ++i) out[i] = (float)((double)a[i] * (kPi / (double)180.0f)); }
+uint32_t orc_stream_size() { return STREAM; }
 void orc_mt19937_head(uint32_t n, float* out) { seq_rng_t r; for (uint32_t i = 0; i < n; ++i) out[i] = r.sample(); }
 void orc_counter_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n_dims, float* out) {
   uint32_t k = path_key(seed, pixel, sample);

@@ -13,6 +13,9 @@
 //                                FLOAT instructions on the reinterpreted integer bits (SURVEY A-20), e.g. the flag test
 //                                (flags & HIT) == HIT of spt.hpp:138 compares denormals
 //   __bscf                       src/utils/compiler.hpp:6-14
+//   parsed_options_t defaults    src/options.hpp:6-43 (spp 16, paths per sample 16, depth 9, output "out.exr"; host_only is left
+//                                uninitialised by the constructor and is not exported)
+//   config::STREAM_SIZE          src/math/config.hpp:6 (the 1024-slot stream every stage of the hot path is sized by)
 // Everything else of the hot path includes Imath / OpenImageIO / OSL headers, which this image
 // does not have: per the build rules that part is "unbuildable here" (no stand-in headers).
 #include <cstddef>
@@ -24,6 +27,8 @@
 #include "math/simd/float8.hpp"
 #include "math/simd/int8.hpp"
 #include "utils/compiler.hpp"
+#include "math/config.hpp"
+#include "options.hpp"
 
 extern "C" {
 
@@ -77,6 +82,18 @@ void ref_int8_select(const float* mask_bits, const int32_t* l, const int32_t* r,
   const simd::float_t<8> m(_mm256_loadu_ps(mask_bits));
   _mm256_storeu_si256((__m256i*)out, simd::select(m, simd::int32_t<8>::loadu(l), simd::int32_t<8>::loadu(r)).v);
 }
+// out[0..6] = samples_per_pixel, paths_per_sample, path_depth, single_threaded, progressive, render_normals, verbose of a
+// default-constructed parsed_options_t; returns the length of its default output name, copied to `name`
+uint32_t ref_options_defaults(uint32_t* out, char* name, uint32_t cap) {
+  const parsed_options_t o;
+  out[0] = o.samples_per_pixel; out[1] = o.paths_per_sample; out[2] = o.path_depth;
+  out[3] = o.single_threaded; out[4] = o.progressive; out[5] = o.render_normals; out[6] = o.verbose;
+  uint32_t n = 0;
+  for (; n < o.output.size() && n + 1 < cap; ++n) name[n] = o.output[n];
+  name[n] = 0;
+  return n;
+}
+uint32_t ref_stream_size() { return config::STREAM_SIZE; }
 uint64_t ref_bscf(uint64_t v, uint64_t* rest) { size_t x = v; size_t i = __bscf(x); *rest = x; return i; }
 
 }  // extern "C"

@@ -125,14 +125,13 @@ struct LdsStack {
 #define PHX_STEPS_PER_REFILL 1
 #endif
 // Sensitivity probes (profiles/README.md), never in the product build: extra FMAs / extra 16-byte loads per node visit.
-// PHX_WG_CURSOR: the chunks of the persistent launch are handed out in two levels.  A WORKGROUP takes 16 chunks' worth of
+// The chunks of the persistent launch are handed out in two levels.  A WORKGROUP takes 16 chunks' worth of
 // consecutive rays from the global cursor at a time; its waves take their chunks from that range through a 64-bit word in LDS
 // (next | end << 32: one ds_add returns a consistent pair).  The wave that finds the range used up fetches the next one
 // (try-lock in LDS, re-check under the lock); waves that lose the race go on traversing and ask again at their next refill.
 // Sixteen waves of one CU then work on neighbouring pixels, and the global cursor takes 1/16 of the atomics.
-#ifndef PHX_WG_CURSOR
-#define PHX_WG_CURSOR 1
-#endif
+// (Round 2 also carried a static XCD-aware split of the queues and per-wave global chunks; both lost to this scheme on every
+// workload and were removed in round 3 — the history is in DESIGN.md section 3.)
 #ifndef PHX_WG_CHUNKS
 #define PHX_WG_CHUNKS 16u  /* chunks in a workgroup's range (fewer when the queue is too short to give every workgroup four ranges) */
 #endif
@@ -152,15 +151,15 @@ struct LdsStack {
 #define PHX_PROBE_VMEM_DWORD 0
 #endif
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
-struct DynQueue {            // DYN: the launch is persistent and every WAVE pulls chunks of both queues on its own
+struct DynQueue {            // the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
-  uint32_t r0, r1;           // PHX_WG_CURSOR: rays in a workgroup's range
-  uint32_t wave_id, num_waves;
+  uint32_t r0, r1;           // rays in a workgroup's range
+  uint32_t num_waves;
   uint32_t* cursor;          // pb.counters + CNT_CURSOR: two global cursors, zeroed by the kernel that filled the queues
 };
-template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */, bool DYN, bool SPILL /* the stack's deep levels live in HBM */>
-__device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q, uint32_t shi, uint32_t chi,
-                                             uint32_t* cursor /* [0] shadow, [1] closest */, uint2* stack_base, uint32_t lds_levels,
+template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */, bool SPILL /* the stack's deep levels live in HBM */>
+__device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q,
+                                             uint32_t* cursor /* LDS: the workgroup's ranges */, uint2* stack_base, uint32_t lds_levels,
                                              uint2* spill_base /* this thread's column of sc.stack_spill */, uint32_t refill_min,
                                              const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0,
                                              const DynQueue dq, const uint8_t* __restrict__ perm_lut) {
@@ -173,10 +172,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
-  uint32_t dlo = 0, dhi = 0;  // DYN: the wave's current chunk [dlo, dhi)
-#if !PHX_WG_CURSOR
-  uint32_t dfirst = 3u;       // "first chunk not yet taken" bits
-#endif
+  uint32_t dlo = 0, dhi = 0;  // the wave's current chunk [dlo, dhi)
 #if PHX_COUNT
   uint32_t cnt_lds[2] = {0, 0}, cnt_mem[2] = {0, 0}, cnt_tri[2] = {0, 0};  // instrumented build: this lane's traversal work
   uint32_t cnt_iter = 0, cnt_nb = 0, cnt_tb = 0, cnt_refill = 0;              // ... and the wave's (wave-uniform)
@@ -192,10 +188,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #endif
       const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
       uint32_t hi, base;
-      if (DYN) {
-        if (dlo >= dhi) {  // chunk used up: the first one is the wave's by position, later ones come from the global cursor
+      {
+        if (dlo >= dhi) {  // chunk used up: take the next one out of the workgroup's range
           const uint32_t c = phase == 0u ? dq.c0 : dq.c1, qn = phase == 0u ? dq.n0 : dq.n1;
-#if PHX_WG_CURSOR
           uint32_t got_lo = 0, got_hi = 0, st = 1;  // st: 0 a chunk, 1 ask again later, 2 this queue is exhausted
           if (lane == leader) {
             unsigned long long* pack = reinterpret_cast<unsigned long long*>(cursor) + phase;
@@ -231,29 +226,12 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)got_lo, (int)leader));
             dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)got_hi, (int)leader));
           } else if (__ballot(active) == 0ull) { __builtin_amdgcn_s_sleep(4); continue; }  // nothing to do but wait for the fetching wave
-#else
-          uint32_t nb = 0;
-          if (dfirst & (1u << phase)) { dfirst = PHX_UNI(dfirst & ~(1u << phase)); nb = dq.wave_id * c; }
-          else {
-            if (lane == leader) nb = atomicAdd(&dq.cursor[phase * CNT_STRIDE], c) + dq.num_waves * c;
-            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nb, (int)leader));
-          }
-          if (nb >= qn) {  // this queue is exhausted
-            phase = PHX_UNI(phase + 1u);
-            if (phase < 2u || __ballot(active) != 0ull) { if (phase < 2u) continue; } else break;
-          } else { dlo = PHX_UNI(nb); dhi = PHX_UNI(min(nb + c, qn)); }
-#endif
         }
         if (phase >= 2u) { hi = 0; base = 0; }
         else {
           const uint32_t take = PHX_UNI(min((uint32_t)__popcll(idle), dhi - dlo));
           base = dlo; hi = dlo + take; dlo = PHX_UNI(dlo + take);
         }
-      } else {
-        hi = phase == 0u ? shi : chi;
-        base = 0;
-        if (lane == leader) base = atomicAdd(&cursor[phase], (uint32_t)__popcll(idle));
-        base = __shfl(base, (int)leader);
       }
       if (!active) {
         // rank of this idle lane in pair-major order (0, 32, 1, 33, ...): consecutive rays go to the two lanes of a pair
@@ -277,7 +255,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           active = true;
         }
       }
-      if (!DYN && base + (uint32_t)__popcll(idle) >= hi) ++phase;  // this range is used up (wave-uniform)
       if (phase < 2u && __ballot(active) == 0ull) continue;  // nothing in flight yet: go fetch from the next range
     }
     if (!__ballot(active)) break;
@@ -419,19 +396,16 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 // Trace kernel: closest-hit rays of ray queue `q` (if do_closest) and any-hit rays of the shadow queue `sq`
 // filled by the previous k_shade (if do_shadow) in ONE launch, so that late bounces with few rays still fill
 // the chip.  Queue lengths are only known on the device.
-//   DYN (default): the launch is persistent — exactly the resident workgroups — and work is handed out in two levels
-//   (PHX_WG_CURSOR): a workgroup takes a range of 16 x 64 consecutive rays from a global cursor (its first range is its own by
+//   The launch is persistent — exactly the resident workgroups — and work is handed out in two levels:
+//   a workgroup takes a range of 16 x 64 consecutive rays from a global cursor (its first range is its own by
 //   position), its waves take 64-ray chunks out of that range through a word in LDS.  Fine chunks keep the drain phase short,
 //   and the global cursor sees one returning atomic per 1024 rays instead of one per chunk (which the wave has to wait for:
 //   with per-wave global chunks 512 rays were the optimum, 64-ray chunks were atomic-bound).  A wave
-//   drains once per launch, not once per slice, and a slow image region is shared by everyone: -6 % trace time.
-//   !DYN: the grid is a fixed multiple of the resident workgroups and every workgroup owns one contiguous range of each
-//   queue, refilled through an LDS cursor.  The split is XCD-aware: workgroups b, b+8, ... share an XCD and its L2, so
-//   each XCD gets a contiguous eighth of the queue.
-// Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][2 cursors].
-template <int BLOCK, bool GEN, bool DYN, bool SPILL = false>
-__global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
-                                                 int interleave, uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t gmul, uint32_t target_chunks) {
+//   drains once per launch, not once per slice, and a slow image region is shared by everyone.
+// Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][8 cursor words][2 KB octant table].
+template <int BLOCK, bool GEN, bool SPILL = false>
+__global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
+                                                 uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
@@ -445,72 +419,36 @@ __global__ void __launch_bounds__(BLOCK, DYN ? 8 : 1) k_trace(DevScene sc, PassB
     if (n_closest) atomicAdd(&pb.stats->rays_closest, (unsigned long long)n_closest);
     if (n_shadow) atomicAdd(&pb.stats->rays_shadow, (unsigned long long)n_shadow);
   }
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  // this workgroup's range of a queue of n rays: XCD share, then an equal slice of it, in 64-ray units
-  auto range = [&](uint32_t n, uint32_t& lo, uint32_t& hi) {
-    // short queues: fewer, longer slices (at least min_chunks 64-ray chunks per workgroup) keep lanes refilled
-    // instead of spreading a handful of rays over every resident wave
-    const uint32_t chunks = (n + 63u) >> 6, per_xcd = (chunks + 7u) >> 3;
-    // The grid is gmul x the resident workgroups (balance for long queues).  A queue too short to give every workgroup of
-    // that grid target_chunks chunks is cut into fewer, longer slices — but never fewer than the resident workgroups — so
-    // that a lane is refilled ~16 times per launch instead of 2-3 times (what a rank of an 8-GPU job sees at every bounce).
-    auto slice = [&](uint32_t total, uint32_t parts) {
-      uint32_t per = (total + parts - 1u) / parts;
-      if (per < target_chunks) per = min(target_chunks, (total + parts / gmul - 1u) / max(parts / gmul, 1u));
-      return max(per, min_chunks);
-    };
-    const uint32_t per_slot = slice(per_xcd, nslots);
-    uint32_t c0, c1;
-    if (interleave) {  // plain contiguous slices in launch order: image regions of different cost spread over all XCDs
-      const uint32_t per_blk = slice(chunks, gridDim.x);
-      c0 = min(blockIdx.x * per_blk, chunks); c1 = min(c0 + per_blk, chunks);
-    } else {
-      c0 = min(xcd * per_xcd + slot * per_slot, chunks);
-      c1 = min(min(xcd * per_xcd + (slot + 1u) * per_slot, (xcd + 1u) * per_xcd), chunks);
-    }
-    lo = c0 << 6; hi = min(c1 << 6, n);
-    if (hi < lo) hi = lo;
-  };
-  uint32_t slo = 0, shi = 0, clo = 0, chi = 0;
+  if (n_shadow == 0u && n_closest == 0u) return;
   DynQueue dq{};
-  if (DYN) {
-    if (n_shadow == 0u && n_closest == 0u) return;
-    dq.n0 = n_shadow; dq.n1 = n_closest;
-    dq.num_waves = gridDim.x * (BLOCK / 64); dq.wave_id = blockIdx.x * (BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // tell the compiler it is wave-uniform
-    dq.cursor = pb.counters + CNT_CURSOR;
-    // ~min_chunks chunks per wave for mid-size queues, 64 .. target_chunks*64 rays each
-    auto chunk_of = [&](uint32_t n) { return min(max((n / (dq.num_waves * max(min_chunks, 1u)) + 63u) & ~63u, 64u), target_chunks * 64u); };
-    dq.c0 = chunk_of(n_shadow); dq.c1 = chunk_of(n_closest);
-    // a workgroup's range: PHX_WG_CHUNKS chunks, fewer when the queue could not give every workgroup four such ranges
-    auto range_of = [&](uint32_t n, uint32_t c) { return c * min(max(n / (gridDim.x * c * 4u), 1u), PHX_WG_CHUNKS); };
-    dq.r0 = range_of(n_shadow, dq.c0); dq.r1 = range_of(n_closest, dq.c1);
-#if PHX_WG_CURSOR
-    if (threadIdx.x == 0) {  // the workgroup's first range is its own by position; read by the waves after the barrier below
-      unsigned long long* pack = reinterpret_cast<unsigned long long*>(cursor);
-      for (uint32_t p = 0; p < 2u; ++p) {
-        const uint32_t cwg = p == 0u ? dq.r0 : dq.r1, qn = p == 0u ? n_shadow : n_closest;
-        const uint32_t lo = min(blockIdx.x * cwg, qn), hi = min(lo + cwg, qn);
-        pack[p] = (unsigned long long)lo | ((unsigned long long)hi << 32);
-        cursor[4 + p] = 0u; cursor[6 + p] = 0u;
-      }
+  dq.n0 = n_shadow; dq.n1 = n_closest;
+  dq.num_waves = gridDim.x * (BLOCK / 64);
+  dq.cursor = pb.counters + CNT_CURSOR;
+  // ~min_chunks chunks per wave for mid-size queues, 64 .. target_chunks*64 rays each
+  auto chunk_of = [&](uint32_t n) { return min(max((n / (dq.num_waves * max(min_chunks, 1u)) + 63u) & ~63u, 64u), target_chunks * 64u); };
+  dq.c0 = chunk_of(n_shadow); dq.c1 = chunk_of(n_closest);
+  // a workgroup's range: PHX_WG_CHUNKS chunks, fewer when the queue could not give every workgroup four such ranges
+  auto range_of = [&](uint32_t n, uint32_t c) { return c * min(max(n / (gridDim.x * c * 4u), 1u), PHX_WG_CHUNKS); };
+  dq.r0 = range_of(n_shadow, dq.c0); dq.r1 = range_of(n_closest, dq.c1);
+  if (threadIdx.x == 0) {  // the workgroup's first range is its own by position; read by the waves after the barrier below
+    unsigned long long* pack = reinterpret_cast<unsigned long long*>(cursor);
+    for (uint32_t p = 0; p < 2u; ++p) {
+      const uint32_t cwg = p == 0u ? dq.r0 : dq.r1, qn = p == 0u ? n_shadow : n_closest;
+      const uint32_t lo = min(blockIdx.x * cwg, qn), hi = min(lo + cwg, qn);
+      pack[p] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+      cursor[4 + p] = 0u; cursor[6 + p] = 0u;
     }
-#endif
-  } else {
-    range(n_shadow, slo, shi);
-    range(n_closest, clo, chi);
-    if (shi <= slo && chi <= clo) return;  // nothing for this workgroup (uniform)
   }
   // stage the top of the tree (the pool is stored breadth first: its first ntop elements ARE the top levels); a staged element
   // keeps an 80-byte stride in LDS (PHX_NODE_LDS_BYTES, bvh8.h)
   const uint4* g4 = reinterpret_cast<const uint4*>(sc.pool);
   for (uint32_t i = threadIdx.x; i < ntop * 4u; i += BLOCK) top[(i >> 2) * (PHX_NODE_LDS_BYTES / 16u) + (i & 3u)] = g4[i];
-  if (!DYN && threadIdx.x == 0) { cursor[0] = slo; cursor[1] = clo; }
 #if PHX_PERM_LUT
   for (uint32_t i = threadIdx.x; i < 2048u; i += BLOCK) perm_lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
 #endif
   __syncthreads();
-  trace_stream<BLOCK, GEN, DYN, SPILL>(sc, pb, q, shi, chi, cursor, stack + threadIdx.x, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
-                                       refill_min, top, ntop, sample0, dq, perm_lut);
+  trace_stream<BLOCK, GEN, SPILL>(sc, pb, q, cursor, stack + threadIdx.x, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
+                                  refill_min, top, ntop, sample0, dq, perm_lut);
 }
 
 // stage-level hook (phx_dev_trace): one ray per lane run to completion with the plain traverse8 loop of bvh8.h.  The per-lane
@@ -1016,7 +954,7 @@ void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_s
 }
 namespace {
 struct TraceEnv {
-  int gmul, gmul0, inter0, dyn, dyn_grid, wg_cap;
+  int grid_mul, wg_cap;
   uint32_t refill, block_env, ntop_env, min_chunks, target_chunks, lds_levels_env;
 };
 const TraceEnv& trace_env() {
@@ -1025,31 +963,28 @@ const TraceEnv& trace_env() {
     // fall back to the default and the workgroup size has to be one the kernels are instantiated for
     auto geti = [](const char* n, int d) { const char* v = getenv(n); const int x = v ? atoi(v) : d; return x < 0 ? d : x; };
     TraceEnv t;
-    t.gmul = geti("PHX_TRACE_GRID", 4); t.gmul0 = geti("PHX_TRACE_GRID0", 16); t.inter0 = geti("PHX_TRACE_INTER0", 1);
-    t.refill = (uint32_t)geti("PHX_REFILL", 12); t.dyn = geti("PHX_TRACE_DYN", 1); t.dyn_grid = geti("PHX_TRACE_DYN_GRID", 1);
+    t.refill = (uint32_t)geti("PHX_REFILL", 12); t.grid_mul = std::max(1, geti("PHX_TRACE_DYN_GRID", 1));
     // 1024-thread workgroups: the CU's LDS holds two copies of the top of the tree instead of eight, so each copy is 4x larger
     t.block_env = (uint32_t)geti("PHX_TRACE_BLOCK", 0); t.ntop_env = (uint32_t)geti("PHX_NTOP", 0);
     if (t.block_env != 0 && t.block_env != 256 && t.block_env != 512 && t.block_env != 1024) t.block_env = 0;
+    t.lds_levels_env = (uint32_t)geti("PHX_LDS_LEVELS", 0);  // stack levels kept in LDS (0 = chosen by trace_plan)
     if (t.lds_levels_env > PHX_MAX_BVH_DEPTH) t.lds_levels_env = 0;
     if (t.refill < 1 || t.refill > 64) t.refill = 12;
     t.min_chunks = (uint32_t)geti("PHX_MIN_CHUNKS", 8);
-    t.lds_levels_env = (uint32_t)geti("PHX_LDS_LEVELS", 0);  // stack levels kept in LDS (0 = chosen by trace_plan)
     t.wg_cap = geti("PHX_TRACE_WG_CAP", 0);  // experiment: at most this many k_trace workgroups per CU (leaves wave slots to another stream)
-    // static split: slices of >= 32 chunks; dynamic: 64-ray chunks out of a workgroup's range of 16 (PHX_WG_CURSOR; k_trace ms per
-    // frame at 100 k: 60.8 — with one global atomic per WAVE and chunk the best was 63.7 at 512 rays: 128 rays 75.7, 256 66.7,
-    // 384 64.4, 768 63.9, 1024 64.2; profiles/r02_n_knob_sweep.log, r02_o_wg_cursor.log)
-    t.target_chunks = (uint32_t)geti("PHX_TARGET_CHUNKS", t.dyn == 0 ? 32 : (PHX_WG_CURSOR ? 1 : 8));
+    // 64-ray chunks out of a workgroup's range of 16 (k_trace ms per frame at 100 k: 60.8 — with one global atomic per WAVE and
+    // chunk the best was 63.7 at 512 rays: 128 rays 75.7, 256 66.7, 384 64.4, 768 63.9, 1024 64.2; profiles/r02_n_knob_sweep.log,
+    // r02_o_wg_cursor.log)
+    t.target_chunks = (uint32_t)std::max(1, geti("PHX_TARGET_CHUNKS", 1));
     return t;
   }();
   return e;
 }
 template <typename F>
 void for_each_trace_kernel(F&& f) {
-  f(reinterpret_cast<const void*>(&k_trace<256, true, true>)); f(reinterpret_cast<const void*>(&k_trace<512, true, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, true, true>));
-  f(reinterpret_cast<const void*>(&k_trace<256, false, true>)); f(reinterpret_cast<const void*>(&k_trace<512, false, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true>));
-  f(reinterpret_cast<const void*>(&k_trace<256, true, false>)); f(reinterpret_cast<const void*>(&k_trace<512, true, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, true, false>));
-  f(reinterpret_cast<const void*>(&k_trace<256, false, false>)); f(reinterpret_cast<const void*>(&k_trace<512, false, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, false>));
-  f(reinterpret_cast<const void*>(&k_trace<1024, true, true, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true, true>));
+  f(reinterpret_cast<const void*>(&k_trace<256, true>)); f(reinterpret_cast<const void*>(&k_trace<512, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, true>));
+  f(reinterpret_cast<const void*>(&k_trace<256, false>)); f(reinterpret_cast<const void*>(&k_trace<512, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, false>));
+  f(reinterpret_cast<const void*>(&k_trace<1024, true, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true>));
   f(reinterpret_cast<const void*>(&k_trace_rays<true>)); f(reinterpret_cast<const void*>(&k_trace_rays<false>));
 }
 }  // namespace
@@ -1079,7 +1014,7 @@ TracePlan trace_plan(const DevScene& sc) {
   // below), but the test on every push and pop costs what the freed LDS buys back on trees whose stacks fit (profiles/README.md):
   // spilling is for trees so deep that the stacks alone would force smaller workgroups and fewer resident waves.
   P.lds_levels = P.levels;
-  if (E.dyn && !E.block_env) {
+  if (!E.block_env) {
     const uint32_t want = E.lds_levels_env ? E.lds_levels_env : (P.levels >= PHX_SPILL_FROM_LEVELS ? PHX_SPILL_LDS_LEVELS : P.levels);
     P.lds_levels = std::max(2u, std::min(P.levels, want));
   }
@@ -1098,8 +1033,8 @@ TracePlan trace_plan(const DevScene& sc) {
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
   // exceed the CU's LDS at full occupancy) is better served by smaller workgroups, whose LDS granularity wastes less
-  P.block = E.block_env ? E.block_env : (E.dyn ? 1024u : 256u);
-  if (E.block_env || !E.dyn || spill) P.wg_per_cu = plan(P.block, P.ntop, P.lds_bytes);  // spilling exists for 1024-thread workgroups only
+  P.block = E.block_env ? E.block_env : 1024u;
+  if (E.block_env || spill) P.wg_per_cu = plan(P.block, P.ntop, P.lds_bytes);  // spilling exists for 1024-thread workgroups only
   else {
     uint32_t best_waves = 0;
     for (uint32_t blk = 1024u; blk >= 256u; blk >>= 1) {
@@ -1109,7 +1044,7 @@ TracePlan trace_plan(const DevScene& sc) {
   }
   if (E.wg_cap > 0 && P.wg_per_cu > (uint32_t)E.wg_cap) P.wg_per_cu = (uint32_t)E.wg_cap;
   if (P.wg_per_cu == 0) P.wg_per_cu = 1;  // deeper than the LDS can hold even with 256 threads: the launch will report the error
-  P.spill_threads = spill ? sc.num_cus * P.wg_per_cu * (uint32_t)std::max(1, E.dyn_grid) * P.block : 0u;
+  P.spill_threads = spill ? sc.num_cus * P.wg_per_cu * (uint32_t)E.grid_mul * P.block : 0u;
   return P;
 }
 
@@ -1118,25 +1053,19 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   const TraceEnv& E = trace_env();
   const TracePlan P = trace_plan(sc);
   const uint32_t block = P.block, ntop = P.ntop, lds = P.lds_bytes, levels = P.lds_levels;
-  const int dyn = E.dyn;
-  const int interleave = camera_rays ? E.inter0 : 0;
-  const uint32_t mul = (uint32_t)std::max(1, dyn ? E.dyn_grid : (camera_rays ? E.gmul0 : E.gmul));
-  uint32_t grid = sc.num_cus * P.wg_per_cu * mul;
+  uint32_t grid = sc.num_cus * P.wg_per_cu * (uint32_t)E.grid_mul;  // persistent: the resident workgroups
   const uint32_t need = (((capacity + block - 1) / block + 7u) / 8u) * 8u;
   grid = std::max(8u, std::min(grid, need));
   const dim3 g(grid), b(block);
   auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, interleave, ntop, levels, E.min_chunks, sample0, mul, E.target_chunks);
+    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, ntop, levels, E.min_chunks, sample0, E.target_chunks);
   };
-  if (dyn && P.lds_levels < P.levels) {  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
-    if (camera_rays) go(&k_trace<1024, true, true, true>); else go(&k_trace<1024, false, true, true>);
-  } else if (dyn) {
-    if (camera_rays) { if (block == 256) go(&k_trace<256, true, true>); else if (block == 512) go(&k_trace<512, true, true>); else go(&k_trace<1024, true, true>); }
-    else { if (block == 256) go(&k_trace<256, false, true>); else if (block == 512) go(&k_trace<512, false, true>); else go(&k_trace<1024, false, true>); }
+  if (P.lds_levels < P.levels) {  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
+    if (camera_rays) go(&k_trace<1024, true, true>); else go(&k_trace<1024, false, true>);
   } else if (camera_rays) {
-    if (block == 256) go(&k_trace<256, true, false>); else if (block == 512) go(&k_trace<512, true, false>); else go(&k_trace<1024, true, false>);
+    if (block == 256) go(&k_trace<256, true>); else if (block == 512) go(&k_trace<512, true>); else go(&k_trace<1024, true>);
   } else {
-    if (block == 256) go(&k_trace<256, false, false>); else if (block == 512) go(&k_trace<512, false, false>); else go(&k_trace<1024, false, false>);
+    if (block == 256) go(&k_trace<256, false>); else if (block == 512) go(&k_trace<512, false>); else go(&k_trace<1024, false>);
   }
 }
 // k_shade / k_shade_g walk the queue with a fixed grid: PHX_SHADE_GRID workgroups per resident slot (never more than the queue's

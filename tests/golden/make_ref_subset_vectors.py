@@ -1,6 +1,6 @@
 """Generates tests/golden/ref_subset_vectors.npz from oracle/_ref/libphx_ref_subset.so — object code
 compiled from the reference's own dependency-free headers (src/math/fresnel.hpp, src/math/trigonometry.hpp,
-src/math/simd/float8.hpp, src/math/simd/int8.hpp, src/utils/compiler.hpp) where they lie under /root/reference.  These are the only
+src/math/simd/float8.hpp, src/math/simd/int8.hpp, src/utils/compiler.hpp, src/options.hpp, src/math/config.hpp) where they lie under /root/reference.  These are the only
 vectors that pin the oracle to outputs of the reference itself; run here (the reference never travels):
 
     make -C oracle ref && python tests/golden/make_ref_subset_vectors.py
@@ -67,7 +67,14 @@ for i in range(16):
     lib.ref_int8_from_float(fp(cvt_in[i]), ip(cvt_out[i]))
 for i in range(32):
     lib.ref_int8_select(fp(mask[i]), ip(il[i]), ip(ir[i]), ip(isel[i]))
+# parsed_options_t defaults (src/options.hpp:6-43) and config::STREAM_SIZE (src/math/config.hpp:6)
+opt = np.zeros(7, np.uint32); name = C.create_string_buffer(64)
+lib.ref_options_defaults.restype = C.c_uint32
+nlen = lib.ref_options_defaults(opt.ctypes.data_as(C.POINTER(C.c_uint32)), name, 64)
+lib.ref_stream_size.restype = C.c_uint32
+stream_size = np.uint32(lib.ref_stream_size())
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_subset_vectors.npz"), cosi=cosi, eta=eta, fresnel=fres, deg=deg, rad=rad,
                     l=l, r=r, mask=mask, select=sel, cmp=cmp.view(np.uint32), minmax=mm, bscf_in=bs_in, bscf_idx=bs_idx, bscf_rest=bs_rest,
-                    int_l=il, int_r=ir, int_op=iop, flag_words=flag_words, flag_test=flag_out, cvt_in=cvt_in, cvt_out=cvt_out, int_select=isel)
+                    int_l=il, int_r=ir, int_op=iop, flag_words=flag_words, flag_test=flag_out, cvt_in=cvt_in, cvt_out=cvt_out, int_select=isel,
+                    options_defaults=opt, options_output=np.frombuffer(name.value[:nlen], np.uint8), stream_size=stream_size)
 print("wrote ref_subset_vectors.npz")

@@ -140,3 +140,17 @@ def test_render_makes_one_device_on_a_multi_gpu_box(monkeypatch):
     assert len(xpu.HipDevice.discover(xpu.Options())) == 4 and made == [0, 1, 2, 3]
     made.clear()
     assert len(xpu.HipDevice.discover(xpu.Options(device_ordinal=2))) == 1 and made == [2]
+
+
+def test_reference_patch_applies():
+    """integration/reference.patch (the maintainer's change list: xpu_t::discover, four mesh_t accessors, the CMake source list,
+    parsed_options_t::host_only) still applies to the reference tree — a dry run, nothing is written"""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")) or not shutil.which("patch"):
+        pytest.skip("no reference tree on this box")
+    r = subprocess.run(["patch", "-p1", "--dry-run", "--batch", "-d", ref, "-i", os.path.join(ROOT, "integration", "reference.patch")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("checking file") == 5

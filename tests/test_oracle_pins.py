@@ -96,6 +96,20 @@ def test_int8_semantics_match_reference_object_code(orc):
     assert np.array_equal(np.where(m, r, l), G["int_select"].reshape(-1))
 
 
+def test_option_defaults_and_stream_size_match_reference_object_code(orc):
+    """parsed_options_t() (src/options.hpp:6-43) and config::STREAM_SIZE (src/math/config.hpp:6) as the reference's own object code
+    reports them: the host mirror's defaults and the restatement's stream length are those numbers"""
+    from phosphorus_mk2_amd import xpu
+    spp, pps, depth, single, progressive, normals, verbose = (int(x) for x in G["options_defaults"])
+    o = xpu.Options()
+    assert (o.samples_per_pixel, o.paths_per_sample, o.path_depth) == (spp, pps, depth) == (16, 16, 9)
+    assert (o.single_threaded, o.render_normals, o.verbose) == (bool(single), bool(normals), bool(verbose)) == (False, False, False)
+    assert progressive == 0 and bytes(G["options_output"]) == b"out.exr"
+    lib = orc.load()
+    lib.orc_stream_size.restype = C.c_uint32
+    assert lib.orc_stream_size() == int(G["stream_size"]) == 1024
+
+
 def test_live_ref_subset_if_present(orc):
     so = os.path.join(ROOT, "oracle", "_ref", "libphx_ref_subset.so")
     if not os.path.exists(so):
