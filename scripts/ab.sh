@@ -12,8 +12,8 @@ done
 for rep in 1 2; do
   for v in "$@"; do
     name=${v%%:*}
-    for tri in 100000 1000000; do
-      PHX_LIB=$R/phosphorus_mk2_amd/libphx_hip_$name.so python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --triangles $tri $BENCH_ARGS > $OUT/${name}_${tri}_$rep.json 2> $OUT/${name}_${tri}_$rep.err || { echo "$name $tri failed"; tail -3 $OUT/${name}_${tri}_$rep.err; }
+    for tri in ${AB_TRIANGLES:-100000 1000000}; do
+      PHX_LIB=$R/phosphorus_mk2_amd/libphx_hip_$name.so python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --one-sink --triangles $tri $BENCH_ARGS > $OUT/${name}_${tri}_$rep.json 2> $OUT/${name}_${tri}_$rep.err || { echo "$name $tri failed"; tail -3 $OUT/${name}_${tri}_$rep.err; }
     done
   done
 done
@@ -24,7 +24,7 @@ for f in sorted(glob.glob("$OUT/*_*_*.json")):
     b=os.path.basename(f)[:-5]; name,tri,rep=b.rsplit("_",2)
     try: d=json.load(open(f))
     except Exception: continue
-    res[(name,tri)].append((d["value"], d["config"]["kernel_ms_per_step"]["trace"], d["config"]["kernel_ms_per_step"]["shade_gen_film"]))
+    res[(name,tri)].append((d["value"], d["config"]["kernel_ms_per_step"]["trace"], d["config"]["kernel_ms_per_step"]["shade"]))
 for (name,tri),v in sorted(res.items(), key=lambda x:(x[0][1],x[0][0])):
     print(f"{tri:>8} {name:<16} " + "  ".join(f"{a:7.0f} Mrays/s trace {b:6.2f} ms shade {c:5.2f} ms" for a,b,c in v))
 PY
