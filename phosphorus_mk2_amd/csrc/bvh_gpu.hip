@@ -127,24 +127,39 @@ __global__ void __launch_bounds__(GB) k_radix_tree(const uint64_t* __restrict__ 
   if (i == 0) parent[0] = 0xffffffffu;
 }
 
-// boxes of all 2n-1 nodes; node ids as above.  flags[] must be zero.
-__global__ void __launch_bounds__(GB) k_fit(const Box6* __restrict__ pbox, const uint32_t* __restrict__ sorted, int n, const uint32_t* __restrict__ left,
-                                            const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* __restrict__ flags,
-                                            Box6* __restrict__ nbox) {
+// Hand-off between the threads of a bottom-up pass (k_fit, k_collapse_dp).  A thread that has finished a subtree RELEASES what it
+// wrote (agent scope: buffer_wbl2 + wait) and then arrives at the parent's flag; the second arrival ACQUIRES (buffer_inv) before it
+// reads what the first one wrote.  Round 2 used a full __threadfence() — write-back AND invalidate — on both sides and one more after
+// the leaf: three per node where one release and one acquire are what the hand-off needs (MI355X_MICROARCH.md, "inter-workgroup
+// visibility": an L2 write-back is microseconds on a multi-XCD part).  The leaf boxes are written by a kernel of their own, so the
+// first arrival of every thread releases nothing.  The explicit wait keeps the flag from overtaking the write-back (the guide's
+// "compiler hazard": the s_waitcnt after buffer_wbl2 may be dropped when the scoreboard is provably empty).
+__device__ __forceinline__ void release_subtree() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void acquire_subtree() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+__global__ void __launch_bounds__(GB) k_leaf_boxes(const Box6* __restrict__ pbox, const uint32_t* __restrict__ sorted, int n, Box6* __restrict__ nbox) {
+  const int k = blockIdx.x * GB + threadIdx.x;
+  if (k < n) nbox[n - 1 + k] = pbox[sorted[k]];
+}
+// boxes of the n-1 inner nodes (the leaves' are there: k_leaf_boxes); node ids as above.  flags[] must be zero.
+__global__ void __launch_bounds__(GB) k_fit(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                            const uint32_t* __restrict__ parent, uint32_t* __restrict__ flags, Box6* __restrict__ nbox) {
   const int k = blockIdx.x * GB + threadIdx.x;
   if (k >= n) return;
-  uint32_t node = (uint32_t)(n - 1 + k);
-  nbox[node] = pbox[sorted[k]];
-  __threadfence();
-  uint32_t p = parent[node];
+  uint32_t p = parent[(uint32_t)(n - 1 + k)];
+  bool wrote = false;
   while (p != 0xffffffffu) {
+    if (wrote) release_subtree();
     if (atomicAdd(&flags[p], 1u) == 0u) return;  // first arrival: the sibling subtree is not finished yet
-    __threadfence();
+    acquire_subtree();
     const Box6 a = nbox[left[p]], b = nbox[right[p]];
     Box6 m;
     for (int x = 0; x < 3; ++x) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
     nbox[p] = m;
-    __threadfence();
+    wrote = true;
     p = parent[p];
   }
 }
@@ -180,20 +195,24 @@ __device__ __forceinline__ uint32_t first_prim(const Tree2& T, uint32_t node) {
 __global__ void __launch_bounds__(DP_BLOCK) k_collapse_dp(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent,
                                                         const Box6* __restrict__ nbox, uint32_t* __restrict__ flags, float* __restrict__ sub,
                                                         uint32_t* __restrict__ cut /* 8 per inner node */, uint8_t* __restrict__ cut_count, float CN, float CT) {
-  __shared__ float s_best[DP_POS * 8 * DP_BLOCK];
-  __shared__ uint8_t s_split[DP_POS * 8 * DP_BLOCK];
+  // 7 slot counts (1 .. 7) per heap position: 30 x 7 x 64 floats + bytes + 30 x 64 node ids = 74.9 KB, TWO blocks per CU
+  // (with 8 columns per position it was 84.5 KB and one 64-thread block per CU: the whole chip ran 256 waves)
+  __shared__ float s_best[DP_POS * 7 * DP_BLOCK];
+  __shared__ uint8_t s_split[DP_POS * 7 * DP_BLOCK];
   __shared__ uint32_t s_node[DP_POS * DP_BLOCK];
   const int k = blockIdx.x * DP_BLOCK + threadIdx.x;
   if (k >= n) return;
   const uint32_t t = threadIdx.x;
-  auto BEST = [&](uint32_t h, int j) -> float& { return s_best[((h - 2u) * 8u + (uint32_t)j) * DP_BLOCK + t]; };
-  auto SPLIT = [&](uint32_t h, int j) -> uint8_t& { return s_split[((h - 2u) * 8u + (uint32_t)j) * DP_BLOCK + t]; };
+  auto BEST = [&](uint32_t h, int j) -> float& { return s_best[((h - 2u) * 7u + (uint32_t)(j - 1)) * DP_BLOCK + t]; };
+  auto SPLIT = [&](uint32_t h, int j) -> uint8_t& { return s_split[((h - 2u) * 7u + (uint32_t)(j - 1)) * DP_BLOCK + t]; };
   auto NODE = [&](uint32_t h) -> uint32_t& { return s_node[(h - 2u) * DP_BLOCK + t]; };
   const uint32_t nleaf0 = (uint32_t)(n - 1);  // ids >= n - 1 are triangles
   uint32_t m = parent[nleaf0 + (uint32_t)k];
+  bool wrote = false;
   while (m != 0xffffffffu) {
+    if (wrote) release_subtree();  // sub / cut / cut_count of the node this thread has just solved
     if (atomicAdd(&flags[m], 1u) == 0u) return;  // first arrival: the sibling subtree is not solved yet
-    __threadfence();
+    acquire_subtree();
     // ---- solve node m
     const Box6 mb = nbox[m];
     float g2[3];
@@ -240,7 +259,7 @@ __global__ void __launch_bounds__(DP_BLOCK) k_collapse_dp(int n, const uint32_t*
       sh[top] = 2 * h + 1; sj[top++] = j - (int)sp; sh[top] = 2 * h; sj[top++] = (int)sp;
     }
     cut_count[m] = (uint8_t)cnt;
-    __threadfence();
+    wrote = true;
     m = parent[m];
   }
 }
@@ -409,7 +428,8 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   HCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
   hipLaunchKernelGGL(k_radix_tree, g, b, 0, stream, keys2, (int)n, left, right, parent, first, last);
   HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));
-  hipLaunchKernelGGL(k_fit, g, b, 0, stream, pbox, sorted, (int)n, left, right, parent, flags, nbox);
+  hipLaunchKernelGGL(k_leaf_boxes, g, b, 0, stream, pbox, sorted, (int)n, nbox);
+  hipLaunchKernelGGL(k_fit, g, b, 0, stream, (int)n, left, right, parent, flags, nbox);
   HCHK(hipGetLastError());
   // the scene grid of the nodelets' origins: from the bounds of the geometry
   uint32_t h_cb[12];

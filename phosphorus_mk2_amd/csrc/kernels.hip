@@ -67,62 +67,6 @@ __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, 
   at_b = cnt_b[nwaves] + cnt_b[wave] + (uint32_t)__popcll(mask_b & below);
 }
 
-// Experiment (PHX_SHADE_BIN, off by default; profiles/README.md "ray coherence"): the same slot allocation, but the workgroup's rays
-// leave in the order of a 6-bit key — direction octant x which half of the scene's box the origin lies in, per axis — so that the
-// 64 rays a k_trace wave picks up next start in the same region and walk the tree the same way round.  Counting sort through LDS:
-// one histogram per queue, scanned by one wave each.  The order inside a bin is the order of arrival (results do not depend on
-// queue order: all state is per path).
-#ifndef PHX_SHADE_BIN
-#define PHX_SHADE_BIN 0
-#endif
-#ifndef PHX_BIN_BITS
-#define PHX_BIN_BITS 2   /* origin cell bits per axis: 2 -> 64 bins, 3 -> 512 bins */
-#endif
-#ifndef PHX_BIN_OCTANT
-#define PHX_BIN_OCTANT 0 /* 1: the direction octant takes the key's low 3 bits (one origin bit per axis fewer) */
-#endif
-__device__ __forceinline__ uint32_t spread3(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); }  // bits 0,1,2 -> 0,3,6
-__device__ __forceinline__ uint32_t coherence_key(const SceneGrid& g, const v3& o, const v3& d) {
-  // the origin's cell on the scene grid (18 bits per axis, bvh8.h), top bits, Morton-interleaved: neighbours in the queue start close together
-  const int B = PHX_BIN_OCTANT ? PHX_BIN_BITS - 1 : PHX_BIN_BITS;
-  const float inv = 1.0f / (float)(1u << (PHX_GRID_BITS - B));
-  auto cell = [&](float x, int a) { const float c = (x - g.lo[a]) / g.cell[a] * inv; return (uint32_t)fminf(fmaxf(c, 0.0f), (float)((1u << B) - 1u)); };
-  const uint32_t m = spread3(cell(o.x, 0)) << 2 | spread3(cell(o.y, 1)) << 1 | spread3(cell(o.z, 2));
-  if (!PHX_BIN_OCTANT) return m;
-  const uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-  return (m << 3) | oct;
-}
-template <int BLOCK, int NB>
-__device__ __forceinline__ void block_append2_binned(bool want_a, uint32_t key_a, uint32_t* counter_a, bool want_b, uint32_t key_b, uint32_t* counter_b,
-                                                     uint32_t* bins /* [2 * NB + 2 * NB / 64 + 2] */, uint32_t& at_a, uint32_t& at_b) {
-  static_assert(BLOCK >= 2 * NB && NB % 64 == 0 && NB <= 512, "one thread per bin of either histogram");
-  constexpr int NW = NB / 64;
-  uint32_t* ha = bins; uint32_t* hb = bins + NB; uint32_t* wt = bins + 2 * NB; uint32_t* base = wt + 2 * NW;
-  for (uint32_t i = threadIdx.x; i < 2u * NB; i += BLOCK) bins[i] = 0;
-  __syncthreads();
-  const uint32_t ra = want_a ? atomicAdd(&ha[key_a], 1u) : 0u, rb = want_b ? atomicAdd(&hb[key_b], 1u) : 0u;
-  __syncthreads();
-  const uint32_t t = threadIdx.x, which = t / NB, bin = t % NB, lane = __lane_id();
-  uint32_t c = 0, incl = 0;
-  if (t < 2u * NB) {
-    c = bins[t]; incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if ((int)lane >= d) incl += up; }
-    if (lane == 63) wt[which * NW + bin / 64] = incl;
-  }
-  __syncthreads();
-  if (t < 2u * NB) {
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { const uint32_t x = wt[which * NW + w]; total += x; if (w < (int)(bin / 64)) before += x; }
-    if (bin == 0) base[which] = total ? atomicAdd(which == 0 ? counter_a : counter_b, total) : 0u;
-    bins[t] = before + incl - c;
-  }
-  __syncthreads();
-  at_a = want_a ? base[0] + ha[key_a] + ra : 0u;
-  at_b = want_b ? base[1] + hb[key_b] + rb : 0u;
-}
-
 // ---- camera rays ------------------------------------------------------------------------------------
 // camera::perspective_kernel_t (kernels/cpu/camera.hpp:80-159), pinhole.  Primary rays are never stored: the first
 // k_trace of a pass and the first k_shade both rebuild the ray of path `path` from the pixel table and the jitter table
@@ -552,8 +496,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   constexpr bool DIFFUSE_ONLY = true;
   constexpr int MAXL = MATS == 2 ? 1 : 8;
   constexpr int PHX_SHADE_BLOCK = PHX_SHADE_BLOCK_D;
-  constexpr int NBINS = 1 << (3 * PHX_BIN_BITS);
-  __shared__ uint32_t lds_cnt[PHX_SHADE_BIN ? 2 * NBINS + 2 * NBINS / 64 + 2 : 2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
+  __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   const uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
   if (i == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0; }  // the next k_trace pulls its chunks from here
@@ -698,12 +641,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   }
   // ---- stream compaction: survivors -> next ray queue, unmasked NEE rays -> shadow queue
   uint32_t no, ns;
-#if PHX_SHADE_BIN
-  block_append2_binned<PHX_SHADE_BLOCK, NBINS>(alive, alive ? coherence_key(sc.grid, nxt_o, nxt_d) : 0u, &pb.counters[(q ^ 1) * CNT_STRIDE],
-                                        want_shadow, want_shadow ? coherence_key(sc.grid, sh_o, sh_d) : 0u, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_cnt, no, ns);
-#else
+  // (the rays leave in thread order.  Sorting the workgroup's survivors by direction octant and / or the Morton cell of their origin
+  // before the append — 64 or 512 bins through LDS — bought k_trace 0.5 ms of 60 and cost this kernel 0.8-1.8 ms of 10 on every
+  // workload, config 4 included: profiles/r03_g_bin_octant_ab.log, r03_i_bin_morton_ab.log; removed after commit "Ray-coherence experiments")
   block_append2<PHX_SHADE_BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_cnt, no, ns);
-#endif
   if (alive) {
     pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
     pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
