@@ -127,18 +127,27 @@ __global__ void __launch_bounds__(GB) k_radix_tree(const uint64_t* __restrict__ 
   if (i == 0) parent[0] = 0xffffffffu;
 }
 
-// Hand-off between the threads of a bottom-up pass (k_fit, k_collapse_dp).  A thread that has finished a subtree RELEASES what it
-// wrote (agent scope: buffer_wbl2 + wait) and then arrives at the parent's flag; the second arrival ACQUIRES (buffer_inv) before it
-// reads what the first one wrote.  Round 2 used a full __threadfence() — write-back AND invalidate — on both sides and one more after
-// the leaf: three per node where one release and one acquire are what the hand-off needs (MI355X_MICROARCH.md, "inter-workgroup
-// visibility": an L2 write-back is microseconds on a multi-XCD part).  The leaf boxes are written by a kernel of their own, so the
-// first arrival of every thread releases nothing.  The explicit wait keeps the flag from overtaking the write-back (the guide's
-// "compiler hazard": the s_waitcnt after buffer_wbl2 may be dropped when the scoreboard is provably empty).
-__device__ __forceinline__ void release_subtree() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// Hand-off between the chains of a bottom-up pass (k_fit, k_collapse_dp).  What one chain writes and another reads inside the
+// same launch — a node's box, a node's sub-cost — is stored and loaded with AGENT-SCOPE relaxed atomics (global_store / global_load
+// with sc1: write-through to the coherence point, never served from a CU's L1), the storing wave waits for its stores
+// (s_waitcnt vmcnt(0)) and only then arrives at the parent's flag with an agent-scope atomic add; the chain whose add comes second
+// reads after its add has returned.  No cache maintenance at all: round 2 ran a full __threadfence() — an L2 write-back plus an L1
+// invalidate — three times per node, 220 of the 250 ms of a 10 M-triangle build (MI355X_MICROARCH.md, "inter-workgroup visibility":
+// hand-off row 1, sc1 stores / sc1 loads, the last adder told by the value its add returned).  Everything else the passes read was
+// written by an earlier kernel; everything else they write (cut[], cut_count[]) is read by a later one.
+__device__ __forceinline__ void store_handoff(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_handoff(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void store_box(Box6* dst, const Box6& b) {
+  float* d = reinterpret_cast<float*>(dst);
+  for (int x = 0; x < 3; ++x) { store_handoff(d + x, b.lo[x]); store_handoff(d + 3 + x, b.hi[x]); }
 }
-__device__ __forceinline__ void acquire_subtree() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ Box6 load_box(const Box6* src) {
+  const float* p = reinterpret_cast<const float*>(src);
+  Box6 b;
+  for (int x = 0; x < 3; ++x) { b.lo[x] = load_handoff(p + x); b.hi[x] = load_handoff(p + 3 + x); }
+  return b;
+}
 
 __global__ void __launch_bounds__(GB) k_leaf_boxes(const Box6* __restrict__ pbox, const uint32_t* __restrict__ sorted, int n, Box6* __restrict__ nbox) {
   const int k = blockIdx.x * GB + threadIdx.x;
@@ -152,13 +161,12 @@ __global__ void __launch_bounds__(GB) k_fit(int n, const uint32_t* __restrict__ 
   uint32_t p = parent[(uint32_t)(n - 1 + k)];
   bool wrote = false;
   while (p != 0xffffffffu) {
-    if (wrote) release_subtree();
+    if (wrote) stores_done();
     if (atomicAdd(&flags[p], 1u) == 0u) return;  // first arrival: the sibling subtree is not finished yet
-    acquire_subtree();
-    const Box6 a = nbox[left[p]], b = nbox[right[p]];
+    const Box6 a = load_box(&nbox[left[p]]), b = load_box(&nbox[right[p]]);
     Box6 m;
     for (int x = 0; x < 3; ++x) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
-    nbox[p] = m;
+    store_box(&nbox[p], m);
     wrote = true;
     p = parent[p];
   }
@@ -187,80 +195,108 @@ __device__ __forceinline__ uint32_t first_prim(const Tree2& T, uint32_t node) {
 //   sub(m) = min over cuts K of m's binary subtree, |K| <= 8, of  sum over c in K of  area(box(c) + 2 grid units of m) * (C_NODE |
 //   C_TRI) + (sub(c) if c is inner)
 // — a local dynamic programme over (descendant, slots), here restricted to cuts within 4 binary levels below m (30 heap
-// positions x 7 slot counts per thread, kept in LDS).  Bottom-up like k_fit: one thread per triangle walks towards the root, the
+// positions x 7 slot counts).  Bottom-up like k_fit: chains start at the triangles and walk towards the root, the
 // second arrival at a node solves it (all its descendants are done by then).  Measured on the host emulation of this tree (Morton
 // splits, PHX_HOST_LBVH=1, Soup(1 M), random rays): node visits per ray 29.8 -> 27.8 against the greedy collapse.
-#define DP_POS 30   /* heap positions 2 .. 31 */
-#define DP_BLOCK 64
-__global__ void __launch_bounds__(DP_BLOCK) k_collapse_dp(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent,
-                                                        const Box6* __restrict__ nbox, uint32_t* __restrict__ flags, float* __restrict__ sub,
-                                                        uint32_t* __restrict__ cut /* 8 per inner node */, uint8_t* __restrict__ cut_count, float CN, float CT) {
-  // 7 slot counts (1 .. 7) per heap position: 30 x 7 x 64 floats + bytes + 30 x 64 node ids = 74.9 KB, TWO blocks per CU
-  // (with 8 columns per position it was 84.5 KB and one 64-thread block per CU: the whole chip ran 256 waves)
-  __shared__ float s_best[DP_POS * 7 * DP_BLOCK];
-  __shared__ uint8_t s_split[DP_POS * 7 * DP_BLOCK];
-  __shared__ uint32_t s_node[DP_POS * DP_BLOCK];
-  const int k = blockIdx.x * DP_BLOCK + threadIdx.x;
-  if (k >= n) return;
-  const uint32_t t = threadIdx.x;
-  auto BEST = [&](uint32_t h, int j) -> float& { return s_best[((h - 2u) * 7u + (uint32_t)(j - 1)) * DP_BLOCK + t]; };
-  auto SPLIT = [&](uint32_t h, int j) -> uint8_t& { return s_split[((h - 2u) * 7u + (uint32_t)(j - 1)) * DP_BLOCK + t]; };
-  auto NODE = [&](uint32_t h) -> uint32_t& { return s_node[(h - 2u) * DP_BLOCK + t]; };
+// Round 3: the programme of one node is solved by a WAVE, not by a lane.  (One lane per chain kept its 30 x 7 table in LDS — 75 KB
+// for 64 threads, two waves per CU, most of their lanes dead after the first arrival: 103 of the 160 ms of a 10 M-triangle build.)
+// A wave owns 64 consecutive leaves of the Morton order and walks their chains one after the other; at a node it is the second to
+// reach, its lanes fetch the 30 descendants within four levels side by side (four dependent rounds of child indices, then every box
+// in ONE load instruction), fill the table's leaf level, and solve the three levels above it with one lane per (position, slot
+// count) pair: 48 / 24 / 12 lanes.  The table is 1.2 KB per wave, so the CU runs its full 32.  Every sum and comparison is the
+// one the serial version made, in the same order: sub[], cut[] and therefore the tree are unchanged.
+#define DP_WAVES 4  /* waves per workgroup */
+__global__ void __launch_bounds__(64 * DP_WAVES) k_collapse_dp(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent,
+                                                             const Box6* __restrict__ nbox, uint32_t* __restrict__ flags, float* __restrict__ sub,
+                                                             uint32_t* __restrict__ cut /* 8 per inner node */, uint8_t* __restrict__ cut_count, float CN, float CT) {
+  __shared__ float s_best[DP_WAVES][32 * 8];
+  __shared__ uint8_t s_split[DP_WAVES][32 * 8];
+  __shared__ uint32_t s_node[DP_WAVES][32];
+  const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
+  float* best = s_best[wave]; uint8_t* split = s_split[wave]; uint32_t* node = s_node[wave];
+  auto BEST = [&](uint32_t h, uint32_t j) -> float& { return best[h * 8u + j]; };
+  auto SPLIT = [&](uint32_t h, uint32_t j) -> uint8_t& { return split[h * 8u + j]; };
+  // LDS traffic between the lanes of ONE wave: the hardware keeps a wave's LDS operations in order; this keeps the compiler from
+  // moving them across the step boundaries
+  auto step = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
   const uint32_t nleaf0 = (uint32_t)(n - 1);  // ids >= n - 1 are triangles
-  uint32_t m = parent[nleaf0 + (uint32_t)k];
-  bool wrote = false;
-  while (m != 0xffffffffu) {
-    if (wrote) release_subtree();  // sub / cut / cut_count of the node this thread has just solved
-    if (atomicAdd(&flags[m], 1u) == 0u) return;  // first arrival: the sibling subtree is not solved yet
-    acquire_subtree();
-    // ---- solve node m
-    const Box6 mb = nbox[m];
-    float g2[3];
-    for (int a = 0; a < 3; ++a) {
-      const double ext = (double)mb.hi[a] - (double)mb.lo[a];
-      int e = -126;
-      if (ext > 0.0) e = (int)ceil(log2(ext * 1.00001 / 255.0));
-      e = max(-126, min(127, e));
-      g2[a] = 2.0f * (float)ldexp(1.0, e);
-    }
-    NODE(2) = left[m]; NODE(3) = right[m];
-    for (uint32_t h = 2; h < 16; ++h) {
-      const uint32_t v = NODE(h);
-      if (v != 0xffffffffu && v < nleaf0) { NODE(2 * h) = left[v]; NODE(2 * h + 1) = right[v]; }
-      else { NODE(2 * h) = 0xffffffffu; NODE(2 * h + 1) = 0xffffffffu; }
-    }
-    for (uint32_t h = 31; h >= 2; --h) {
-      const uint32_t v = NODE(h);
-      if (v == 0xffffffffu) continue;
-      const Box6 b = nbox[v];
-      const float dx = b.hi[0] - b.lo[0] + g2[0], dy = b.hi[1] - b.lo[1] + g2[1], dz = b.hi[2] - b.lo[2] + g2[2];
-      const float aq = 2.0f * (dx * dy + dy * dz + dz * dx);
-      if (v >= nleaf0) { for (int j = 1; j <= 7; ++j) { BEST(h, j) = aq * CT; SPLIT(h, j) = 0; } continue; }
-      const float single = aq * CN + sub[v];  // as ONE slot: an 8-wide node of its own
-      BEST(h, 1) = single; SPLIT(h, 1) = 0;
-      for (int j = 2; j <= 7; ++j) {
-        float r = single; uint8_t sp = 0;
-        if (h < 16) {
-          for (int kk = 1; kk < j; ++kk) { const float c = BEST(2 * h, kk) + BEST(2 * h + 1, j - kk); if (c < r) { r = c; sp = (uint8_t)kk; } }
+  const uint32_t k0 = (blockIdx.x * DP_WAVES + wave) * 64u;
+  for (uint32_t k = k0; k < k0 + 64u && k < (uint32_t)n; ++k) {
+    uint32_t m = parent[nleaf0 + k];
+    bool wrote = false;
+    while (m != 0xffffffffu) {
+      if (wrote) stores_done();  // sub[] of the node this wave has just solved
+      uint32_t arrived = 0;
+      if (lane == 0) arrived = atomicAdd(&flags[m], 1u);
+      arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+      if (arrived == 0u) break;  // first arrival: the sibling subtree is not solved yet
+      // ---- the descendants of m within four levels, by heap position (2, 3 = m's children)
+      if (lane < 2) node[2 + lane] = lane == 0 ? left[m] : right[m];
+      step();
+#pragma unroll
+      for (uint32_t first = 4; first <= 16; first <<= 1) {
+        if (lane < first) {
+          const uint32_t h = first + lane, v = node[h >> 1];
+          node[h] = (v != 0xffffffffu && v < nleaf0) ? ((h & 1u) ? right[v] : left[v]) : 0xffffffffu;
         }
-        BEST(h, j) = r; SPLIT(h, j) = sp;
+        step();
       }
+      // ---- one lane per position: its box on m's grid, its cost as ONE slot
+      const Box6 mb = nbox[m];
+      float g2[3];
+      for (int a = 0; a < 3; ++a) {
+        const double ext = (double)mb.hi[a] - (double)mb.lo[a];
+        int e = -126;
+        if (ext > 0.0) e = (int)ceil(log2(ext * 1.00001 / 255.0));
+        e = max(-126, min(127, e));
+        g2[a] = 2.0f * (float)ldexp(1.0, e);
+      }
+      if (lane >= 2 && lane < 32) {
+        const uint32_t h = lane, v = node[h];
+        if (v != 0xffffffffu) {
+          const Box6 b = nbox[v];
+          const float dx = b.hi[0] - b.lo[0] + g2[0], dy = b.hi[1] - b.lo[1] + g2[1], dz = b.hi[2] - b.lo[2] + g2[2];
+          const float aq = 2.0f * (dx * dy + dy * dz + dz * dx);
+          // a triangle costs aq * CT in any number of slots; an inner node as ONE slot is an 8-wide node of its own; below the
+          // fourth level nothing is split, so that is also its cost in more slots
+          const float one = v >= nleaf0 ? aq * CT : aq * CN + load_handoff(&sub[v]);
+          const uint32_t upto = (v >= nleaf0 || h >= 16u) ? 7u : 1u;
+          for (uint32_t j = 1; j <= upto; ++j) { BEST(h, j) = one; SPLIT(h, j) = 0; }
+        }
+      }
+      step();
+      // ---- levels 3, 2, 1 of the heap: lane -> (position, slot count 2 .. 7)
+#pragma unroll
+      for (uint32_t first = 8; first >= 2; first >>= 1) {
+        if (lane < first * 6u) {
+          const uint32_t h = first + lane / 6u, j = 2u + lane % 6u, v = node[h];
+          if (v != 0xffffffffu && v < nleaf0) {
+            float r = BEST(h, 1); uint8_t sp = 0;
+            for (uint32_t kk = 1; kk < j; ++kk) { const float c = BEST(2 * h, kk) + BEST(2 * h + 1, j - kk); if (c < r) { r = c; sp = (uint8_t)kk; } }
+            BEST(h, j) = r; SPLIT(h, j) = sp;
+          }
+        }
+        step();
+      }
+      // ---- m itself: all 8 slots, split between its two children; then the cut that achieves it (depth <= 4: at most 8 pending items)
+      if (lane == 0) {
+        float r = 3.0e38f; uint32_t bk = 1;
+        for (uint32_t kk = 1; kk < 8; ++kk) { const float c = BEST(2, kk) + BEST(3, 8 - kk); if (c < r) { r = c; bk = kk; } }
+        store_handoff(&sub[m], r);
+        uint32_t sh[8], sj[8]; int top = 0; uint32_t cnt = 0;
+        sh[top] = 3; sj[top++] = 8 - bk; sh[top] = 2; sj[top++] = bk;
+        while (top > 0) {
+          --top; const uint32_t h = sh[top], j = sj[top];
+          const uint8_t sp = SPLIT(h, j);
+          if (sp == 0) { cut[(size_t)m * 8 + cnt++] = node[h]; continue; }
+          sh[top] = 2 * h + 1; sj[top++] = j - sp; sh[top] = 2 * h; sj[top++] = sp;
+        }
+        cut_count[m] = (uint8_t)cnt;
+      }
+      step();  // the table is rewritten by the next node
+      wrote = true;
+      m = parent[m];
     }
-    float r = 3.0e38f; int bk = 1;
-    for (int kk = 1; kk < 8; ++kk) { const float c = BEST(2, kk) + BEST(3, 8 - kk); if (c < r) { r = c; bk = kk; } }
-    sub[m] = r;
-    // the cut that achieves it: walk the recorded splits (depth <= 4: at most 8 pending items)
-    uint32_t sh[8]; int sj[8]; int top = 0; uint32_t cnt = 0;
-    sh[top] = 3; sj[top++] = 8 - bk; sh[top] = 2; sj[top++] = bk;
-    while (top > 0) {
-      --top; const uint32_t h = sh[top]; const int j = sj[top];
-      const uint8_t sp = SPLIT(h, j);
-      if (sp == 0) { cut[(size_t)m * 8 + cnt++] = NODE(h); continue; }
-      sh[top] = 2 * h + 1; sj[top++] = j - (int)sp; sh[top] = 2 * h; sj[top++] = (int)sp;
-    }
-    cut_count[m] = (uint8_t)cnt;
-    wrote = true;
-    m = parent[m];
   }
 }
 
@@ -461,7 +497,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
     if (!sub || !cut || !cut_count) { std::snprintf(err, errlen, "hipMalloc failed (collapse tables)"); cleanup(); return 1; }
     HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));  // k_fit is done with its arrival flags
     const float cn = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f;
-    hipLaunchKernelGGL(k_collapse_dp, dim3((n + DP_BLOCK - 1) / DP_BLOCK), dim3(DP_BLOCK), 0, stream, (int)n, left, right, parent, nbox, flags, sub, cut, cut_count, cn, 1.0f);
+    hipLaunchKernelGGL(k_collapse_dp, dim3((n + 64 * DP_WAVES - 1) / (64 * DP_WAVES)), dim3(64 * DP_WAVES), 0, stream, (int)n, left, right, parent, nbox, flags, sub, cut, cut_count, cn, 1.0f);
     HCHK(hipGetLastError());
   }
   uint32_t count = 1, depth = 0; int cur = 0;

@@ -300,6 +300,28 @@ def test_device_built_bvh_matches_host_built(xpu, orc, name, n):
     assert max_pixel_l2(devb, ref) < L2_TOL and bits_equal(devb[..., :3], ref[..., :3])
 
 
+def test_device_builder_handoff_under_load(xpu):
+    """The bottom-up passes of the device builder (k_fit, k_collapse_dp) hand boxes and sub-costs from chain to chain inside one
+    launch with agent-scope stores / loads and no cache maintenance (bvh_gpu.hip: store_handoff / load_handoff).  A stale read there
+    would change a box or a cut, hence the tree: the same scene built over and over — uneven trees, other work on the GPU in between
+    — must give the same node count, depth and modelled cost every time, and the film of the first build."""
+    from phosphorus_mk2_amd import scenes
+    for sc in (scenes.showroom(300000, width=96, height=64), scenes.soup(400000, width=96, height=64)):
+        seen, films = set(), []
+        for rep in range(10):
+            dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=2, paths_per_sample=1, bvh_builder="device"))
+            dev.preprocess(sc)
+            st = dev.stats()
+            seen.add((st["bvh_nodes"], st["bvh_depth"], st["bvh_cost_model"], st["bvh_bytes"]))
+            if rep in (0, 9):
+                tiles = xpu.Tiles.make(96, 64, 32); film = xpu.Film(96, 64, 4)
+                dev.start(sc, xpu.FrameState(3, tiles, film, native_sink=True)); dev.join()
+                films.append(film.data.copy())
+            dev.close()
+        assert len(seen) == 1, seen
+        assert bits_equal(films[0], films[1])
+
+
 @pytest.mark.parametrize("builder", ["host", "device"])
 def test_stress_geometry(xpu, orc, builder):
     """zero-area, coincident (exact distance ties), 2^-20-sized, 1e4-sized and flat triangles: both builders must give the
