@@ -196,7 +196,7 @@ def count_work(triangles, width, height, spp, builder):
 
 def load_capture(tag):
     """the newest committed capture profiles/r*_<tag>_pmc.json (scripts/summarize_profile.py) -> (dict, relative path)"""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), key=lambda f: (os.path.getmtime(f), f)) if tag else []
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json"))) if tag else []  # rNN_<letter>_...: the name orders them
     if not files:
         return None, None
     return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
