@@ -732,6 +732,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       if (base + (uint32_t)k * BLOCK >= count) break;  // workgroup-uniform: the slots past the end of the queue sort behind every live one
       const uint32_t i = base + perm[k * BLOCK + threadIdx.x];
       const bool live = i < count;
+      // (Requesting the hit record and the ray of round k + 1 while round k is shaded — the window's order is fixed by then — costs
+      // 5-12 VGPRs and bought 1.2 of 42.7 ms: profiles/r03_q_prefetch_ab.log.  Not kept.)
       // Live ranges are kept short on purpose (the kernel is register-bound: 128 VGPRs as one block of code): radiance and the
       // normals channel are written as soon as the hit is known; the light's record is re-read after the closure evaluation instead
       // of being held across it; the NEE ray is in its queue before roulette and BSDF sampling start.
