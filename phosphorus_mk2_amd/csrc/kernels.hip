@@ -158,33 +158,6 @@ struct LdsStack {
 #define PHX_PROBE_VMEM_DWORD 0
 #endif
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
-// PHX_TRACE_SHARE — the drain of a launch.  When the queues are exhausted a wave is left with a few long rays and many idle lanes,
-// and the launch ends when the longest of them does: 0.2-0.4 ms per launch, whatever the launch's size.  In
-// that phase an idle lane takes the BOTTOM entry of a busy lane's stack — a group of sibling subtrees the ray has still to visit —
-// and traverses it as that ray's helper: same ray, the owner's current tbest, its own stack.  A ray's subtrees are independent
-// given a conservative tbest, and the closest hit is the minimum over all tested triangles by (t, primitive index), so the result
-// does not depend on who tested what.  Helpers follow the owner's tbest (one shuffle per iteration), report back when their subtree
-// is done (the owner merges by the same tie rule as mt_intersect), and the owner finishes when its own stack is empty AND no helper
-// is out.  Only original rays give work away (one level); the camera-ray launch (GEN) does not take part: it has the smallest drain
-// and no register to spare.
-#ifndef PHX_TRACE_SHARE
-#define PHX_TRACE_SHARE 1
-#endif
-#ifndef PHX_TRACE_WATCHDOG
-#define PHX_TRACE_WATCHDOG (1u << 22)  /* loop iterations after which a k_trace wave exits with DevStats::watchdog set: every wave must reach its exit */
-#endif
-#ifndef PHX_SHARE_MIN_IDLE
-#define PHX_SHARE_MIN_IDLE 4u
-#endif
-__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t n) {  // position of the n-th (0-based) set bit of m
-  uint32_t pos = 0;
-#pragma unroll
-  for (uint32_t w = 32; w >= 1; w >>= 1) {
-    const uint32_t c = (uint32_t)__popcll(m & ((1ull << w) - 1ull));
-    if (n >= c) { n -= c; m >>= w; pos += w; }
-  }
-  return pos;
-}
 struct DynQueue {            // the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
   uint32_t r0, r1;           // rays in a workgroup's range
@@ -204,13 +177,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   float tbest = 0.f, hu = 0.f, hv = 0.f;
   uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, th = 0, path = 0;
   int sp = 0;
-  constexpr bool SHARE = PHX_TRACE_SHARE && !GEN;
-  // SHARE: bits 0-7 the bottom of this lane's stack (the entries below it have been given away), bits 8-15 helpers still out,
-  // bit 16 occluded (an any-hit ray whose own or a helper's test found a hit while helpers were out).  A helper lane keeps
-  // 0x80000000 | owner's lane in `idx` (it writes no result of its own, so idx and path are free).
-  uint32_t hs = 0;
-  bool hdone = false;  // SHARE: this helper has stopped in this iteration and has not been merged yet
-  uint2* const stack_wave = stack_base - lane;  // lane 0's column of the stack: lane l's entry k is stack_wave[k * BLOCK + l]
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
   uint32_t dlo = 0, dhi = 0;  // the wave's current chunk [dlo, dhi)
@@ -220,9 +186,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   uint32_t cnt_idle = 0, cnt_pend = 0;
   uint32_t cnt_push[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  uint32_t guard = 0;  // wave-uniform iteration count: a wave that loops PHX_TRACE_WATCHDOG times (a frame needs ~2e4) gives up and says so
   for (;;) {
-    if (++guard > PHX_TRACE_WATCHDOG) { if (lane == 0) atomicAdd(&pb.stats->watchdog, 1ull); break; }
     // ---- refill idle lanes from the workgroup's cursors
     const unsigned long long idle = __ballot(!active);
     if (phase < 2u && (uint32_t)__popcll(idle) >= refill_min) {
@@ -292,7 +256,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
             tbest = b.w; path = f2u(a.w);
           }
-          hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my; hs = 0;
+          hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
           ng_base = 0; ng_hits = 0x80000000u; th = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
           any = phase == 0u;
           active = true;
@@ -301,46 +265,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       if (phase < 2u && __ballot(active) == 0ull) continue;  // nothing in flight yet: go fetch from the next range
     }
     if (!__ballot(active)) break;
-    if (SHARE && phase >= 2u) {
-      // ---- the drain: idle lanes take the bottom stack entry of a busy ORIGINAL ray
-      const unsigned long long act = __ballot(active), idle_m = ~act;
-      const uint32_t bottom = hs & 0xffu;
-      const unsigned long long donors = __ballot(active && (idx >> 31) == 0u && (uint32_t)sp > bottom && (!SPILL || bottom < lds_levels) &&
-                                                 ((hs >> 8) & 0xffu) < 200u && (hs & 0x10000u) == 0u);
-      const uint32_t nidle = (uint32_t)__popcll(idle_m), n = min(nidle, (uint32_t)__popcll(donors));
-      if (nidle >= PHX_SHARE_MIN_IDLE && n > 0u) {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const bool is_donor = (donors >> lane) & 1ull;
-        const uint32_t my_rank = (uint32_t)__popcll((active ? donors : idle_m) & below);
-        const bool take = !active && my_rank < n, give = is_donor && my_rank < n;
-        const int src = take ? (int)nth_set_bit(donors, my_rank) : (int)lane;
-        const float ox = __shfl(r.o.x, src), oy = __shfl(r.o.y, src), oz = __shfl(r.o.z, src);
-        const float dx = __shfl(r.d.x, src), dy = __shfl(r.d.y, src), dz = __shfl(r.d.z, src);
-        const float tb = __shfl(tbest, src);
-        const uint32_t hp = (uint32_t)__shfl((int)hprim, src), hsd = (uint32_t)__shfl((int)hs, src);
-        const unsigned long long any_m = __ballot(any);
-        if (take) {
-          const uint2 e = stack_wave[(hsd & 0xffu) * BLOCK + (uint32_t)src];
-          r = make_ray_ctx(v3(ox, oy, oz), v3(dx, dy, dz));
-          tbest = tb; hprim = hp; hu = 0.f; hv = 0.f; htri = 0xffffffffu;
-          idx = 0x80000000u | (uint32_t)src; any = (any_m >> src) & 1ull;
-          ng_base = e.x; ng_hits = e.y; th = 0; sp = 0; hs = 0;
-          active = true;
-        }
-        if (give) hs += 0x101u;  // the bottom moves up by one entry; one more helper is out
-      }
-      // ---- helpers follow their owner: its tbest (and the primitive that set it), or its occlusion
-      const unsigned long long helpers = __ballot(active && (idx >> 31) != 0u);
-      if (helpers) {
-        const int o = (int)(idx & 63u);
-        const float tb_o = __shfl(tbest, o);
-        const uint32_t hp_o = (uint32_t)__shfl((int)hprim, o), hs_o = (uint32_t)__shfl((int)hs, o);
-        if (active && (idx >> 31) != 0u) {
-          if (any) { if (hs_o & 0x10000u) { active = false; hdone = true; } }
-          else if (tb_o < tbest || (tb_o == tbest && hp_o < hprim)) { tbest = tb_o; hprim = hp_o; htri = 0xffffffffu; }  // whatever this helper had found is beaten
-        }
-      }
-    }
 #if PHX_COUNT
     ++cnt_iter;
     if (__ballot(active && th == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
@@ -433,29 +357,21 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 #endif
         if (mt_intersect(T, r.o, r.d, tbest, hprim, us, vs, ds)) {
           tbest = ds; hu = us; hv = vs; htri = ti; hprim = T.prim;
-          if (any) {  // occluded: nothing to add
-            if (!SHARE || (hs & 0xff00u) == 0u) { active = false; if (SHARE && (idx >> 31) != 0u) hdone = true; }
-            else { hs |= 0x10000u; sp = (int)(hs & 0xffu); ng_hits = 0; th = 0; }  // helpers are still out: wait for them, they stop by themselves
-          }
+          if (any) active = false;  // occluded: nothing to add
         }
       }
       // ---- pop the next group, or finish the ray
       if (active && th == 0 && ng_hits <= 0x00ffffffu) {
-        if (sp == (SHARE ? (int)(hs & 0xffu) : 0)) {
-          if (SHARE && (idx >> 31) != 0u) { active = false; hdone = true; }  // a helper: its owner merges what it found
-          else if (!SHARE || (hs & 0xff00u) == 0u) {
-            if (any) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
-              if (!SHARE || (hs & 0x10000u) == 0u) {
-                const float4 cc = pb.sc[idx];
-                float4 rr = pb.pr[path];
-                rr.x += cc.x; rr.y += cc.y; rr.z += cc.z;
-                pb.pr[path] = rr;
-              }
-            } else {
-              pb.hit[idx] = make_float4(tbest, hu, hv, u2f(htri));
-            }
-            active = false;
-          }  // else: helpers are still out — this lane stays active and comes back here until they have reported
+        if (sp == 0) {
+          if (any) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
+            const float4 cc = pb.sc[idx];
+            float4 rr = pb.pr[path];
+            rr.x += cc.x; rr.y += cc.y; rr.z += cc.z;
+            pb.pr[path] = rr;
+          } else {
+            pb.hit[idx] = make_float4(tbest, hu, hv, u2f(htri));
+          }
+          active = false;
         } else {
           --sp;
           uint2 e;
@@ -464,26 +380,6 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           ng_base = e.x; ng_hits = e.y;
         }
       }
-    }
-    if (SHARE && phase >= 2u) {
-      // ---- helpers that stopped in this iteration report to their owners (a scalar loop: several may share one owner)
-      unsigned long long fin = __ballot(hdone);
-      while (fin) {
-        const int H = __ffsll((long long)fin) - 1;
-        fin &= fin - 1ull;
-        const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)idx, H) & 63u;
-        const float t_h = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(tbest), H));
-        const uint32_t hu_h = (uint32_t)__builtin_amdgcn_readlane((int)f2u(hu), H), hv_h = (uint32_t)__builtin_amdgcn_readlane((int)f2u(hv), H);
-        const uint32_t tri_h = (uint32_t)__builtin_amdgcn_readlane((int)htri, H), prim_h = (uint32_t)__builtin_amdgcn_readlane((int)hprim, H);
-        if (lane == R) {
-          hs -= 0x100u;
-          if (tri_h != 0xffffffffu) {
-            if (any) { hs |= 0x10000u; sp = (int)(hs & 0xffu); ng_hits = 0; th = 0; }  // occluded: this lane's own traversal is over
-            else if (t_h < tbest || (t_h == tbest && prim_h < hprim)) { tbest = t_h; hu = u2f(hu_h); hv = u2f(hv_h); htri = tri_h; hprim = prim_h; }
-          }
-        }
-      }
-      hdone = false;
     }
   }
 #if PHX_COUNT
