@@ -655,6 +655,7 @@ int phx_device::run_frame() {
   stats.wave_iters = ds.wave_iters; stats.node_block_execs = ds.node_block_execs; stats.tri_block_execs = ds.tri_block_execs; stats.refills = ds.refills;
   stats.idle_lane_iters = ds.idle_lane_iters; stats.tri_pending_lane_iters = ds.tri_pending_lane_iters;
   for (int k = 0; k < 8; ++k) stats.stack_pushes[k] = ds.stack_pushes[k];
+  if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace: " + std::to_string(ds.watchdog) + " wave(s) hit the iteration watchdog: the frame is incomplete");
   for (auto& te : timed) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));

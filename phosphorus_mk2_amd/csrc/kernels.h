@@ -63,6 +63,7 @@ struct DevStats {
   // wave-level: loop iterations, executions of the node block / the triangle block (a block runs when ANY lane needs it)
   unsigned long long wave_iters, node_block_execs, tri_block_execs, refills;
   unsigned long long idle_lane_iters, tri_pending_lane_iters;
+  unsigned long long watchdog;         // k_trace waves that gave up after PHX_TRACE_WATCHDOG iterations: 0, or the frame is reported as failed
   unsigned long long stack_pushes[8];  // instrumented: pushes onto the per-lane group stack by the depth they land at (7 = 7 and deeper)  // instrumented: lanes without a ray / with triangles still pending at the node block, summed over iterations
 };
 

@@ -158,6 +158,9 @@ struct LdsStack {
 #define PHX_PROBE_VMEM_DWORD 0
 #endif
 #define PHX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* wave-uniform by construction: keep it in an SGPR */
+#ifndef PHX_TRACE_WATCHDOG
+#define PHX_TRACE_WATCHDOG (1u << 22)  /* loop iterations after which a k_trace wave exits with DevStats::watchdog set (a launch needs ~1e4): every wave reaches its exit */
+#endif
 struct DynQueue {            // the launch is persistent and every WAVE pulls chunks of both queues on its own
   uint32_t n0, n1, c0, c1;   // queue lengths and chunk sizes (0 shadow, 1 closest), wave-uniform
   uint32_t r0, r1;           // rays in a workgroup's range
@@ -186,7 +189,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   uint32_t cnt_idle = 0, cnt_pend = 0;
   uint32_t cnt_push[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+  uint32_t guard = 0;  // wave-uniform (an SGPR): iterations of this wave
   for (;;) {
+    if (++guard > PHX_TRACE_WATCHDOG) { if (lane == 0) atomicAdd(&pb.stats->watchdog, 1ull); break; }
     // ---- refill idle lanes from the workgroup's cursors
     const unsigned long long idle = __ballot(!active);
     if (phase < 2u && (uint32_t)__popcll(idle) >= refill_min) {
