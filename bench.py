@@ -403,6 +403,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a ONE-GPU box (PHX_BENCH_REHEARSAL=1, never set by the driver): every rank uses GPU 0 and the
+    # film reduce runs on gloo, because two RCCL ranks cannot share a device.  Everything else — tile shard, device films, the reduce,
+    # max-over-ranks timing, the rays summed over ranks — is the code the real N-GPU run takes.  The number it prints is not a result.
+    rehearsal = os.environ.get("PHX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     use_dist = world > 1 or args.force_dist
     dist = None
     # torch first: libphx_hip.so then binds to the HIP runtime torch already loaded (one runtime per process).  torch is plumbing
@@ -411,7 +417,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if use_dist:
         from phosphorus_mk2_amd import dist as pdist
-        dist = pdist.init_process_group("nccl", rank, world, torch.device("cuda", local_rank))
+        dist = pdist.init_process_group("gloo" if rehearsal else "nccl", rank, world, None if rehearsal else torch.device("cuda", local_rank))
     from phosphorus_mk2_amd import scenes, xpu
     xpu.load_library()  # raises if the HIP extension is missing: no fallback
 
@@ -491,8 +497,8 @@ def main():
         value_other = rays_o / (time.perf_counter() - t1) / 1e6
     rays_local = acc["closest"] + acc["shadow"]
     if use_dist:
-        elapsed = pdist.max_over_ranks(elapsed, "cuda")
-        rays_total = pdist.sum_over_ranks(rays_local, "cuda")
+        elapsed = pdist.max_over_ranks(elapsed, "cpu" if rehearsal else "cuda")
+        rays_total = pdist.sum_over_ranks(rays_local, "cpu" if rehearsal else "cuda")
     else:
         rays_total = float(rays_local)
 
@@ -503,7 +509,7 @@ def main():
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", **({"rehearsal": "all ranks on GPU 0, gloo reduce: not a scaling result"} if rehearsal else {}),
             "value_film": "host (PCIe inside the timed region, --host-film)" if film_dev is None else "hbm (device film: nothing crosses PCIe inside a step)",
             "value_host_film": value if film_dev is None else value_other, "value_hbm_film": value_other if film_dev is None else value,
             "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "

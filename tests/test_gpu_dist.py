@@ -59,3 +59,29 @@ def test_two_ranks_on_one_gpu_sum_to_the_one_process_film(tmp_path):
     assert bits_equal(got["film"], full) and full[..., :3].max() > 0.05
     assert got["closest"] == st["rays_closest"] and got["shadow"] == st["rays_shadow"]
     assert got["ntiles"] == st["tiles"] == 20 and got["mine"] == 10  # 5 x 4 tiles, half of them per rank
+
+
+@pytest.mark.timeout(600)
+def test_bench_multi_rank_path_rehearsed_on_one_gpu():
+    """bench.py's N > 1 code — torch.distributed.run launch, tile shard by rank, zero-initialised device films, ONE reduce to rank 0,
+    max-over-ranks time, rays summed over ranks, one JSON line from rank 0 — rehearsed with two ranks on this box's one GPU
+    (PHX_BENCH_REHEARSAL=1: both ranks on GPU 0, the reduce on gloo).  The traced rays and the film must be those of the N = 1 run."""
+    import json
+    import subprocess
+    common = ["--triangles", "3000", "--width", "160", "--height", "96", "--spp", "9", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--one-sink"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, PHX_BENCH_REHEARSAL="1")
+    port = 29700 + (os.getpid() % 200)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["film_collective"].startswith("reduce") and "rehearsal" in d2
+    assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and d2["config"]["camera_samples_per_step"] == 160 * 96 * 9
+    assert d2["config"]["film_mean"] == d1["config"]["film_mean"] and d2["config"]["film_finite"]
+    assert d2["roofline"]["frac"] is None and d2["cpu_baseline"] is None  # reported at N = 1 only
