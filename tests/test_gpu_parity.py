@@ -322,6 +322,40 @@ def test_device_builder_handoff_under_load(xpu):
         assert bits_equal(films[0], films[1])
 
 
+def test_device_builder_handoff_beside_a_running_render(xpu):
+    """The same hand-offs under UNEVEN load, caches warm with other work: while another device object on the same GPU renders frame
+    after frame (its own stream), the builder makes the same tree every time.  (The guide: test a hand-off under uneven load — idle
+    chips and cold caches hide stale reads.)"""
+    import threading
+    from phosphorus_mk2_amd import scenes
+    busy = scenes.soup(60000, width=256, height=192)
+    worker = xpu.HipDevice.make(xpu.Options(samples_per_pixel=16, paths_per_sample=1))
+    worker.preprocess(busy)
+    stop = threading.Event(); frames = [0]
+
+    def render_loop():
+        tiles = xpu.Tiles.make(256, 192, 32); film = xpu.Film(256, 192, 4)
+        while not stop.is_set():
+            tiles.reset()
+            worker.start(busy, xpu.FrameState(1, tiles, film, native_sink=True)); worker.join()
+            frames[0] += 1
+
+    t = threading.Thread(target=render_loop); t.start()
+    try:
+        sc = scenes.showroom(500000, width=64, height=64)
+        seen = set()
+        for rep in range(12):
+            dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=1, paths_per_sample=1, bvh_builder="device"))
+            dev.preprocess(sc)
+            st = dev.stats()
+            seen.add((st["bvh_nodes"], st["bvh_depth"], st["bvh_cost_model"], st["bvh_bytes"]))
+            dev.close()
+    finally:
+        stop.set(); t.join(); worker.close()
+    assert len(seen) == 1, seen
+    assert frames[0] >= 2  # the render really ran beside the builds
+
+
 @pytest.mark.parametrize("builder", ["host", "device"])
 def test_stress_geometry(xpu, orc, builder):
     """zero-area, coincident (exact distance ties), 2^-20-sized, 1e4-sized and flat triangles: both builders must give the
