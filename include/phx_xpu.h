@@ -64,10 +64,10 @@ typedef struct phx_options {
   uint32_t bvh_builder;       /* PHX_BVH_AUTO (default), PHX_BVH_DEVICE_LBVH or PHX_BVH_HOST_SAH: where preprocess builds the tree */
   uint32_t reserved[5];
 } phx_options;
-/* AUTO: binned SAH on the host cores up to 2 M triangles (ahead by 3-5 % in trace time on mesh-like scenes, builds 1 M triangles
- * in ~0.6 s), LBVH on the device above (10 M triangles in 0.27 s instead of 7 s, and no slower to trace at that size) —
- * cpu_t::preprocess rebuilds its accelerator on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the
- * interface's cost. */
+/* AUTO = the device builder (LBVH over extended Morton codes + the optimal 8-wide collapse) for every scene with at least 64
+ * triangles: 1 M triangles in 12 ms and 10 M in 40 ms against 0.6 s / 7 s of the host's binned-SAH builder, and since round 3 its
+ * trees trace as fast or faster on every scene measured (profiles/r03_z_emc_probe.log).  cpu_t::preprocess rebuilds its accelerator
+ * on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the interface's cost.  HOST_SAH stays selectable. */
 enum { PHX_BVH_AUTO = 0, PHX_BVH_DEVICE_LBVH = 1, PHX_BVH_HOST_SAH = 2 };
 
 /* ---- scene: what the device reads through scene_t (src/scene.hpp:14-50) --------------- */

@@ -331,14 +331,14 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   int rc;
   if ((rc = d->d_prim_material.upload(prim_material))) return rc;
   const auto t_bvh0 = std::chrono::steady_clock::now();
-  // PHX_BVH_AUTO: binned SAH on the host cores up to 2 M triangles, Morton LBVH on the device above (10 M: 0.27 s instead of 7 s).
-  // Both trees get the optimal 8-wide collapse, whose objective (bvh_cost_model in the stats) was tried as the way to choose
-  // between them and does not rank them: it calls the host tree 6-13 % cheaper everywhere, while measured trace times differ by
-  // -5..+5 % (host ahead on mesh-like scenes, device ahead on the 1 M soup; profiles/r02_l_auto_probe.log).
+  // PHX_BVH_AUTO: the device builder (bvh_gpu.hip) unless the scene is tiny.  Round 2 kept the host's binned SAH for scenes up to 2 M
+  // triangles because its trees traced 3-5 % faster on mesh-like scenes; with extended Morton codes (the size of a primitive as a
+  // fourth coordinate) the device trees are as fast or faster everywhere measured — soups -2 ... -7 % k_trace time, the showroom
+  // -3 % — and they are built in milliseconds (profiles/r03_z_emc_probe.log, r03_za_builder_ab.log).
   const uint32_t builder = d->opt.bvh_builder;
   const uint32_t ntri = (uint32_t)prim_material.size();
   if (builder > PHX_BVH_HOST_SAH) return fail(PHX_ERR_ARG, "unknown bvh_builder");
-  const bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri <= 2000000u);
+  const bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri < 64u);
   const bool want_device = !want_host;
   GpuBvh g{};
   if (want_device) {
