@@ -249,17 +249,25 @@ __device__ __forceinline__ uint32_t first_prim(const Tree2& T, uint32_t node) {
 // Round 3: the programme of one node is solved by a WAVE, not by a lane.  (One lane per chain kept its 30 x 7 table in LDS — 75 KB
 // for 64 threads, two waves per CU, most of their lanes dead after the first arrival: 103 of the 160 ms of a 10 M-triangle build.)
 // A wave owns 64 consecutive leaves of the Morton order and walks their chains one after the other; at a node it is the second to
-// reach, its lanes fetch the 30 descendants within four levels side by side (four dependent rounds of child indices, then every box
-// in ONE load instruction), fill the table's leaf level, and solve the three levels above it with one lane per (position, slot
+// reach, its lanes fetch the 30 descendants within DP_LEVELS = 4 levels side by side (four dependent rounds of child indices, then
+// every box in ONE load instruction), fill the table's leaf level, and solve the levels above it with one lane per (position, slot
 // count) pair: 48 / 24 / 12 lanes.  The table is 1.2 KB per wave, so the CU runs its full 32.  Every sum and comparison is the
 // one the serial version made, in the same order: sub[], cut[] and therefore the tree are unchanged.
 #define DP_WAVES 4  /* waves per workgroup */
+#ifndef DP_LEVELS
+#define DP_LEVELS 4 /* binary levels below a node within which its cut is searched: 2^(DP_LEVELS+1) - 2 = 30 heap positions, one lane each.
+                       5 levels (62 positions) lower the modelled cost (20 931 -> 20 727 at 10 M triangles) and RAISE k_trace's time on
+                       every scene tried (+7 % on Soup 1 M, +4 % on the showroom: profiles/r03_zg_dp_levels.log) - deeper trees, one
+                       more stack level in LDS - although on the host builder's SAH trees the same knob (PHX_DP_HEAP) helps by 1-3 % */
+#endif
+#define DP_NPOS (2u << DP_LEVELS) /* heap positions 2 .. DP_NPOS - 1 */
 __global__ void __launch_bounds__(64 * DP_WAVES) k_collapse_dp(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent,
                                                              const Box6* __restrict__ nbox, uint32_t* __restrict__ flags, float* __restrict__ sub,
                                                              uint32_t* __restrict__ cut /* 8 per inner node */, uint8_t* __restrict__ cut_count, float CN, float CT) {
-  __shared__ float s_best[DP_WAVES][32 * 8];
-  __shared__ uint8_t s_split[DP_WAVES][32 * 8];
-  __shared__ uint32_t s_node[DP_WAVES][32];
+  static_assert(DP_NPOS <= 64, "one lane per heap position");
+  __shared__ float s_best[DP_WAVES][DP_NPOS * 8];
+  __shared__ uint8_t s_split[DP_WAVES][DP_NPOS * 8];
+  __shared__ uint32_t s_node[DP_WAVES][DP_NPOS];
   const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
   float* best = s_best[wave]; uint8_t* split = s_split[wave]; uint32_t* node = s_node[wave];
   auto BEST = [&](uint32_t h, uint32_t j) -> float& { return best[h * 8u + j]; };
@@ -282,7 +290,7 @@ __global__ void __launch_bounds__(64 * DP_WAVES) k_collapse_dp(int n, const uint
       if (lane < 2) node[2 + lane] = lane == 0 ? left[m] : right[m];
       step();
 #pragma unroll
-      for (uint32_t first = 4; first <= 16; first <<= 1) {
+      for (uint32_t first = 4; first <= DP_NPOS / 2; first <<= 1) {
         if (lane < first) {
           const uint32_t h = first + lane, v = node[h >> 1];
           node[h] = (v != 0xffffffffu && v < nleaf0) ? ((h & 1u) ? right[v] : left[v]) : 0xffffffffu;
@@ -299,7 +307,7 @@ __global__ void __launch_bounds__(64 * DP_WAVES) k_collapse_dp(int n, const uint
         e = max(-126, min(127, e));
         g2[a] = 2.0f * (float)ldexp(1.0, e);
       }
-      if (lane >= 2 && lane < 32) {
+      if (lane >= 2 && lane < DP_NPOS) {
         const uint32_t h = lane, v = node[h];
         if (v != 0xffffffffu) {
           const Box6 b = nbox[v];
@@ -308,16 +316,16 @@ __global__ void __launch_bounds__(64 * DP_WAVES) k_collapse_dp(int n, const uint
           // a triangle costs aq * CT in any number of slots; an inner node as ONE slot is an 8-wide node of its own; below the
           // fourth level nothing is split, so that is also its cost in more slots
           const float one = v >= nleaf0 ? aq * CT : aq * CN + load_handoff(&sub[v]);
-          const uint32_t upto = (v >= nleaf0 || h >= 16u) ? 7u : 1u;
+          const uint32_t upto = (v >= nleaf0 || h >= DP_NPOS / 2) ? 7u : 1u;
           for (uint32_t j = 1; j <= upto; ++j) { BEST(h, j) = one; SPLIT(h, j) = 0; }
         }
       }
       step();
-      // ---- levels 3, 2, 1 of the heap: lane -> (position, slot count 2 .. 7)
+      // ---- the levels of the heap above the last, bottom-up: lane -> (position, slot count 2 .. 7), 64 pairs at a time
 #pragma unroll
-      for (uint32_t first = 8; first >= 2; first >>= 1) {
-        if (lane < first * 6u) {
-          const uint32_t h = first + lane / 6u, j = 2u + lane % 6u, v = node[h];
+      for (uint32_t first = DP_NPOS / 4; first >= 2; first >>= 1) {
+        for (uint32_t item = lane; item < first * 6u; item += 64u) {
+          const uint32_t h = first + item / 6u, j = 2u + item % 6u, v = node[h];
           if (v != 0xffffffffu && v < nleaf0) {
             float r = BEST(h, 1); uint8_t sp = 0;
             for (uint32_t kk = 1; kk < j; ++kk) { const float c = BEST(2 * h, kk) + BEST(2 * h + 1, j - kk); if (c < r) { r = c; sp = (uint8_t)kk; } }
