@@ -220,119 +220,6 @@ __global__ void __launch_bounds__(GB) k_fit(int n, const uint32_t* __restrict__ 
   }
 }
 
-// ---- PLOC: the binary tree by parallel locally-ordered clustering (Meister & Bittner 2018) ---------------------------------------
-// An alternative to the Karras radix tree over the same sorted keys (PHX_PLOC=1).  Clusters start as the primitives in Morton order;
-// every round, each cluster looks PLOC_R places to the left and right for the neighbour whose union with it has the smallest surface
-// area; clusters that choose EACH OTHER merge into a new node that takes the place of the left one, the right one's place closes up
-// (an order-preserving compaction), until one cluster is left.  Bottom-up and greedy on surface area, where the radix tree splits by
-// the bits of the key whatever the boxes look like.  Node ids: internal nodes are handed out from n - 2 downwards, so the last merge
-// makes node 0, the root every later pass expects; leaves are n - 1 + (position in Morton order), as in the radix tree.
-#ifndef PLOC_R
-#define PLOC_R 16
-#endif
-#define PLOC_B 256
-__device__ __forceinline__ float union_area(const Box6& a, const Box6& b) {
-  const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]),
-              dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
-  return dx * dy + dy * dz + dz * dx;
-}
-// nearest neighbour of every cluster within PLOC_R positions: boxes of the block's range + a halo of PLOC_R on both sides in LDS
-__global__ void __launch_bounds__(PLOC_B) k_ploc_nn(const uint32_t* __restrict__ cid, uint32_t m, const Box6* __restrict__ nbox, uint32_t* __restrict__ nn) {
-  __shared__ Box6 tile[PLOC_B + 2 * PLOC_R];
-  const int b0 = (int)(blockIdx.x * PLOC_B) - PLOC_R;
-  for (int t = threadIdx.x; t < PLOC_B + 2 * PLOC_R; t += PLOC_B) {
-    const int g = b0 + t;
-    if (g >= 0 && g < (int)m) tile[t] = nbox[cid[g]];
-  }
-  __syncthreads();
-  const int i = (int)(blockIdx.x * PLOC_B + threadIdx.x);
-  if (i >= (int)m) return;
-  const Box6 me = tile[threadIdx.x + PLOC_R];
-  // Ties (coincident or identical boxes: whole runs of equal areas) go to the partner i ^ 1 if it is among the minima, else to the
-  // leftmost: both members of a pair see the same area, so (2k, 2k + 1) choose each other and a run of equals halves every round
-  // instead of losing one pair per round; and the leftmost member of any globally smallest pair always ends up in a mutual choice,
-  // so every round merges at least one pair.
-  float best = FLT_MAX; int bj = -1;
-  const int lo = max(i - PLOC_R, 0), hi = min(i + PLOC_R, (int)m - 1), buddy = i ^ 1;
-  for (int j = lo; j <= hi; ++j) {
-    if (j == i) continue;
-    const float a = union_area(me, tile[j - b0]);
-    if (a < best || (a == best && j == buddy)) { best = a; bj = j; }
-  }
-  nn[i] = (uint32_t)bj;
-}
-// merge mutual pairs; out[i] = the cluster now standing at position i, or NONE where the right member of a pair stood.  The new
-// nodes' ids come from one counter per WAVE-ful of merges (an atomic per merge would be n of them on one address).
-__global__ void __launch_bounds__(PLOC_B) k_ploc_merge(const uint32_t* __restrict__ cid, uint32_t m, const uint32_t* __restrict__ nn, Box6* __restrict__ nbox,
-                                                       uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ parent,
-                                                       uint32_t* __restrict__ next_id /* ids still free: [0, *next_id) */, uint32_t* __restrict__ out,
-                                                       uint32_t* __restrict__ block_count) {
-  __shared__ uint32_t wave_cnt[PLOC_B / 64];
-  const uint32_t i = blockIdx.x * PLOC_B + threadIdx.x;
-  bool valid = false, merge = false;
-  uint32_t j = 0;
-  if (i < m) {
-    j = nn[i];
-    const bool mutual = nn[j] == i;
-    merge = mutual && i < j;
-    valid = !(mutual && i > j);
-  }
-  const unsigned long long mm = __ballot(merge);
-  uint32_t base = 0;
-  if (mm) {
-    if (__lane_id() == (uint32_t)__ffsll((long long)mm) - 1u) base = atomicSub(next_id, (uint32_t)__popcll(mm));
-    base = (uint32_t)__shfl((int)base, __ffsll((long long)mm) - 1);
-  }
-  uint32_t mine = i < m ? cid[i] : 0u;
-  if (merge) {
-    const uint32_t id = base - 1u - (uint32_t)__popcll(mm & ((1ull << __lane_id()) - 1ull));
-    const uint32_t a = cid[i], c = cid[j];
-    left[id] = a; right[id] = c; parent[a] = id; parent[c] = id;
-    const Box6 x = nbox[a], y = nbox[c];
-    Box6 u;
-    for (int k = 0; k < 3; ++k) { u.lo[k] = fminf(x.lo[k], y.lo[k]); u.hi[k] = fmaxf(x.hi[k], y.hi[k]); }
-    nbox[id] = u;
-    if (id == 0u) parent[0] = 0xffffffffu;
-    mine = id;
-  }
-  if (i < m) out[i] = valid ? mine : 0xffffffffu;
-  // how many clusters of this block stay: the compaction's first level
-  const unsigned long long vm = __ballot(valid);
-  if (__lane_id() == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(vm);
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < PLOC_B / 64; ++w) t += wave_cnt[w]; block_count[blockIdx.x] = t; }
-}
-// exclusive scan of up to a few 10^4 block counts by ONE workgroup; total -> *m_out
-__global__ void __launch_bounds__(1024) k_ploc_scan(uint32_t* __restrict__ block_count, uint32_t nblocks, uint32_t* __restrict__ m_out) {
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (nblocks + 1023u) / 1024u, t0 = threadIdx.x * per;
-  uint32_t sum = 0;
-  for (uint32_t k = t0; k < min(t0 + per, nblocks); ++k) sum += block_count[k];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t acc = 0; for (int k = 0; k < 1024; ++k) { const uint32_t c = part[k]; part[k] = acc; acc += c; } *m_out = acc; }
-  __syncthreads();
-  uint32_t acc = part[threadIdx.x];
-  for (uint32_t k = t0; k < min(t0 + per, nblocks); ++k) { const uint32_t c = block_count[k]; block_count[k] = acc; acc += c; }
-}
-// order-preserving compaction of out[] into the next round's cluster array
-__global__ void __launch_bounds__(PLOC_B) k_ploc_compact(const uint32_t* __restrict__ out, uint32_t m, const uint32_t* __restrict__ block_offset, uint32_t* __restrict__ cid_next) {
-  __shared__ uint32_t wave_off[PLOC_B / 64];
-  const uint32_t i = blockIdx.x * PLOC_B + threadIdx.x;
-  const uint32_t v = i < m ? out[i] : 0xffffffffu;
-  const bool valid = v != 0xffffffffu;
-  const unsigned long long vm = __ballot(valid);
-  if (__lane_id() == 0) wave_off[threadIdx.x >> 6] = (uint32_t)__popcll(vm);
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t acc = 0; for (int w = 0; w < PLOC_B / 64; ++w) { const uint32_t c = wave_off[w]; wave_off[w] = acc; acc += c; } }
-  __syncthreads();
-  if (valid) cid_next[block_offset[blockIdx.x] + wave_off[threadIdx.x >> 6] + (uint32_t)__popcll(vm & ((1ull << __lane_id()) - 1ull))] = v;
-}
-__global__ void __launch_bounds__(GB) k_ploc_init(uint32_t n, uint32_t* __restrict__ cid) {
-  const uint32_t k = blockIdx.x * GB + threadIdx.x;
-  if (k < n) cid[k] = n - 1u + k;
-}
-
 struct Tree2 {
   const uint32_t* left; const uint32_t* right; const uint32_t* first; const uint32_t* last; const Box6* nbox; const uint32_t* sorted;
   int n;
@@ -589,9 +476,6 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const 
   pool[n8].node = nd;
 }
 
-#ifndef PHX_PLOC_DEFAULT
-#define PHX_PLOC_DEFAULT 0
-#endif
 #define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::snprintf(err, errlen, "%s: %s", #x, hipGetErrorString(e_)); cleanup(); return 1; } } while (0)
 
 }  // namespace
@@ -632,32 +516,12 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   if (!temp) { std::snprintf(err, errlen, "hipMalloc failed (sort scratch)"); cleanup(); return 1; }
   HCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
   hipLaunchKernelGGL(k_leaf_boxes, g, b, 0, stream, pbox, sorted, (int)n, nbox);
-  static const int use_ploc = [] { const char* v = getenv("PHX_PLOC"); return v ? atoi(v) : PHX_PLOC_DEFAULT; }();
-  if (use_ploc) {
-    // the Morton keys and the sort's ping-pong buffers are free now: clusters (x2), neighbours, merged array, block counts, counters
-    uint32_t* cidA = reinterpret_cast<uint32_t*>(keys); uint32_t* cidB = cidA + n;
-    uint32_t* nn = reinterpret_cast<uint32_t*>(keys2); uint32_t* merged = nn + n;
-    uint32_t* block_count = first;                      // n words: far more than the blocks of any round
-    uint32_t* ctr = last;                               // [0] ids still free, [1] clusters after this round
-    hipLaunchKernelGGL(k_ploc_init, g, b, 0, stream, n, cidA);
-    const uint32_t init_ctr[2] = {n - 1u, n};
-    HCHK(hipMemcpyAsync(ctr, init_ctr, sizeof(init_ctr), hipMemcpyHostToDevice, stream));
-    uint32_t m = n;
-    for (int round = 0; m > 1; ++round) {
-      if (round > 4096) { std::snprintf(err, errlen, "PLOC does not converge"); cleanup(); return 1; }
-      const uint32_t nblk = (m + PLOC_B - 1) / PLOC_B;
-      hipLaunchKernelGGL(k_ploc_nn, dim3(nblk), dim3(PLOC_B), 0, stream, cidA, m, nbox, nn);
-      hipLaunchKernelGGL(k_ploc_merge, dim3(nblk), dim3(PLOC_B), 0, stream, cidA, m, nn, nbox, left, right, parent, ctr, merged, block_count);
-      hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, stream, block_count, nblk, ctr + 1);
-      hipLaunchKernelGGL(k_ploc_compact, dim3(nblk), dim3(PLOC_B), 0, stream, merged, m, block_count, cidB);
-      uint32_t m_next = 0;
-      HCHK(hipMemcpyAsync(&m_next, ctr + 1, 4, hipMemcpyDeviceToHost, stream));
-      HCHK(hipStreamSynchronize(stream));
-      if (m_next >= m || m_next == 0) { std::snprintf(err, errlen, "PLOC round %d: %u -> %u clusters", round, m, m_next); cleanup(); return 1; }
-      m = m_next;
-      std::swap(cidA, cidB);
-    }
-  } else {
+  // (The binary tree is Karras' radix tree over the extended Morton keys.  PLOC — bottom-up merging of the clusters whose union has the
+  // smallest surface area, radius 16 — was built in its place and measured: lower modelled cost (-1 % soups, -9 % showroom) but 15 %
+  // MORE node visits and 24 % more triangle tests per ray on the soups, k_trace +17 ... +35 %, +1 ... +2 % on the showroom: merged
+  // boxes overlap, and a closest-hit traversal pays for overlap that a surface-area cost does not see.  profiles/r03_zh_ploc_probe.log;
+  // the code is in the history at "PLOC (parallel locally-ordered clustering) ...".)
+  {
     hipLaunchKernelGGL(k_radix_tree, g, b, 0, stream, keys2, (int)n, left, right, parent, first, last);
     HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));
     hipLaunchKernelGGL(k_fit, g, b, 0, stream, (int)n, left, right, parent, flags, nbox);
