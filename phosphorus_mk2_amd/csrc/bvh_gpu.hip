@@ -75,19 +75,14 @@ __device__ __forceinline__ uint64_t spread21(uint32_t x) {  // 21 bits -> every 
 
 // Extended Morton codes (Vinkler, Bittner, Havran 2017): the SIZE of a primitive is a fourth coordinate of the sort key, so that the
 // few huge triangles of a scene (a room's walls around finely tessellated objects) separate from the small ones near the top of the
-// tree instead of inflating the box of every node they share a Morton cell with.  PHX_EMC = 2 (default): "xyzs" fifteen times —
-// 15 bits per axis + 15 size bits, size = box diagonal / scene diagonal, linear.  Against plain 63-bit Morton codes (0): k_trace
-// -2.4 % (Soup 100 k), -2.1 % (1 M), -2.6 % (config 4), -5.5 % (showroom 1 M); against the host's binned-SAH tree: -2.4 / -4.5 % on
-// the soups, -3 ... -4 % on the showroom (profiles/r03_x_emc_probe.log ... r03_za_builder_ab.log).  1: "xyzxyzs" nine times (18 + 9
-// bits): half the gain; a square-root size scale or a gain of 4 / 16 / 64 on the size: worse.
+// tree instead of inflating the box of every node they share a Morton cell with.  The key is "xyzs" fifteen times — 15 bits per
+// axis + 15 size bits, size = box diagonal / scene diagonal, linear.  Against plain 63-bit Morton codes (PHX_EMC=0): k_trace -2.4 %
+// (Soup 100 k), -2.1 % (1 M), -2.6 % (config 4), -5.5 % (showroom 1 M); against the host's binned-SAH tree: -2.4 / -4.5 % on the
+// soups, -3 ... -4 % on the showroom (profiles/r03_x_emc_probe.log ... r03_za_builder_ab.log).  Measured and worse: "xyzxyzs" nine
+// times (half the gain), a square-root size scale, a gain of 4 / 16 / 64 on the size, no size bit in the first 1 / 2 / 4 groups,
+// the size bit in front of its group (r03_y, r03_z, r03_zj_emc_skip.log, r03_zk_emc_first.log).
 #ifndef PHX_EMC
-#define PHX_EMC 2
-#endif
-#ifndef PHX_EMC_GAIN
-#define PHX_EMC_GAIN 1.0f
-#endif
-#ifndef PHX_EMC_SQRT
-#define PHX_EMC_SQRT 0
+#define PHX_EMC 1
 #endif
 __global__ void __launch_bounds__(GB) k_morton(const Box6* __restrict__ pbox, uint32_t n, const uint32_t* __restrict__ cb, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const uint32_t i = blockIdx.x * GB + threadIdx.x;
@@ -105,31 +100,15 @@ __global__ void __launch_bounds__(GB) k_morton(const Box6* __restrict__ pbox, ui
     d2 += e * e; D2 += E * E;
   }
 #if PHX_EMC
-  // size = the box diagonal relative to the scene's (PHX_EMC_SQRT: its square root, which spreads the small sizes)
-  float rel = D2 > 0.0f ? sqrtf(d2 / D2) : 0.0f;
-#if PHX_EMC_SQRT
-  rel = sqrtf(rel);
-#endif
+  const float rel = D2 > 0.0f ? sqrtf(d2 / D2) : 0.0f;  // the box diagonal relative to the scene's
+  const uint32_t sz = (uint32_t)fminf(rel * 32768.0f, 32767.0f);
   uint64_t key = 0;
-#if PHX_EMC == 2
-  const uint32_t sz = (uint32_t)fminf(rel * (32768.0f * PHX_EMC_GAIN), 32767.0f);  // "xyzs" fifteen times: 15 bits per axis + 15 size bits
 #pragma unroll
-  for (int g = 0; g < 15; ++g) {
+  for (int g = 0; g < 15; ++g) {  // group g: bit 20 - g of every axis, then bit 14 - g of the size
     const int bit = 20 - g;
     key = (key << 3) | (uint64_t)(((q[0] >> bit) & 1u) << 2 | ((q[1] >> bit) & 1u) << 1 | ((q[2] >> bit) & 1u));
     key = (key << 1) | (uint64_t)((sz >> (14 - g)) & 1u);
   }
-#else
-  const uint32_t sz = (uint32_t)fminf(rel * 512.0f, 511.0f);
-#pragma unroll
-  for (int g = 0; g < 9; ++g) {  // group g takes bits (20 - 2g, 19 - 2g) of each axis and bit (8 - g) of the size
-    for (int h = 0; h < 2; ++h) {
-      const int bit = 20 - 2 * g - h;
-      key = (key << 3) | (uint64_t)(((q[0] >> bit) & 1u) << 2 | ((q[1] >> bit) & 1u) << 1 | ((q[2] >> bit) & 1u));
-    }
-    key = (key << 1) | (uint64_t)((sz >> (8 - g)) & 1u);
-  }
-#endif
   keys[i] = key;
 #else
   keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
