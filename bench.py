@@ -237,13 +237,14 @@ def capture_diagnostics(cap, src, kernel, units_in_capture):
 
 def roofline(acc, steps, work, tag, ref_visits):
     """k_trace.  acc: rays and k_trace ms summed over `steps` timed frames of THIS run; work: count_work() of one frame (instrumented
-    build, same frame); tag: which committed capture holds this workload's counters."""
+    build, same frame); tag: which committed capture holds this workload's counters.  The camera rays are k_trace_primary's (its own
+    kernel, its own HIP events): rays, work and time here are k_trace's alone."""
     nl = max(1, acc["launches"])
     t_frame = acc["closest_ms"] * 1e-3 / steps          # k_trace seconds per frame (HIP events, this run)
     t_launch = acc["closest_ms"] * 1e-3 / nl
-    rays_c, rays_s = acc["closest"] / steps, acc["shadow"] / steps
+    rays_c, rays_s = (acc["closest"] - acc.get("primary_rays", 0)) / steps, acc["shadow"] / steps
     roof = {"kernel": "k_trace", "launches_per_step": nl / steps, "avg_launch_ms": t_launch * 1e3,
-            "rays_per_launch": (acc["closest"] + acc["shadow"]) / nl, "kernel_rays_per_s": (rays_c + rays_s) / t_frame,
+            "rays_per_launch": (rays_c + rays_s) * steps / nl, "kernel_rays_per_s": (rays_c + rays_s) / t_frame,
             "bound": "valu", "achieved": None, "peak": None, "unit": "G node-visit equivalents/s", "frac": None, "traffic": None}
     peak, peak_src = committed_valu_peak()
     if work and "error" not in work and peak:
@@ -322,13 +323,34 @@ def shade_roofline(acc, steps, st, tag):
 
 
 def new_acc():
-    return {"closest": 0, "shadow": 0, "camera": 0, "closest_ms": 0.0, "shade_ms": 0.0, "shade_kernel_ms": 0.0, "shade_launches": 0, "launches": 0, "frame_ms": 0.0}
+    return {"closest": 0, "shadow": 0, "camera": 0, "closest_ms": 0.0, "shade_ms": 0.0, "shade_kernel_ms": 0.0, "shade_launches": 0, "launches": 0, "frame_ms": 0.0,
+            "primary_ms": 0.0, "primary_launches": 0, "primary_rays": 0}
+
+
+def kernel_ms(acc, steps):
+    """HIP-event milliseconds per step by kernel: k_trace_primary (camera rays), k_trace (every other ray), k_shade / k_shade_g, the rest"""
+    return {"primary": acc["primary_ms"] / steps, "trace": acc["closest_ms"] / steps, "shade": acc["shade_kernel_ms"] / steps,
+            "begin_pass_film": (acc["shade_ms"] - acc["shade_kernel_ms"]) / steps}
+
+
+def primary_record(acc, steps, work):
+    """k_trace_primary: the camera rays of every pass, one packet walk per 64-256 rays (its work is not k_trace's: reported beside the roofline)"""
+    if not acc["primary_launches"]:
+        return None
+    t = acc["primary_ms"] * 1e-3
+    rec = {"kernel": "k_trace_primary", "launches_per_step": acc["primary_launches"] / steps, "ms_per_step": acc["primary_ms"] / steps,
+           "rays_per_step": acc["primary_rays"] / steps, "rays_per_s": acc["primary_rays"] / t}
+    if work and "error" not in work and work.get("primary"):
+        rec["packets"] = work["primary"]
+    return rec
 
 
 def add_stats(acc, st):
     acc["closest"] += st["rays_closest"]; acc["shadow"] += st["rays_shadow"]; acc["camera"] += st["camera_samples"]
     acc["closest_ms"] += st["closest_ms"]; acc["shade_ms"] += st["shade_ms"]; acc["launches"] += st["trace_launches"]
     acc["shade_kernel_ms"] += st["shade_kernel_ms"]; acc["shade_launches"] += st["shade_launches"]; acc["frame_ms"] += st["frame_ms"]
+    acc["primary_ms"] += st["primary_ms"]; acc["primary_launches"] += st["primary_launches"]
+    acc["primary_rays"] += st["camera_samples"] if st["primary_launches"] else 0
 
 
 def make_scene(scenes, kind, triangles, width, height):
@@ -380,12 +402,12 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
     rec = {"workload": name, "value": value, "value_host_film": value_host, "unit": "Mrays/s", "ms_per_step": ms, "steps": 2, "rays_per_step": (acc["closest"] + acc["shadow"]) / 2,
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
-           "kernel_ms_per_step": {"trace": acc["closest_ms"] / 2, "shade": acc["shade_kernel_ms"] / 2, "begin_pass_film": (acc["shade_ms"] - acc["shade_kernel_ms"]) / 2},
-           "film_finite": bool(np.isfinite(film).all())}
+           "kernel_ms_per_step": kernel_ms(acc, 2), "film_finite": bool(np.isfinite(film).all())}
     tag = workload_tag(kind, triangles, width, height, args.depth)
     if kind == "zoo":
         rec["roofline"] = shade_roofline(acc, 2, st, tag)
         rec["roofline_k_trace"] = roofline(acc, 2, None, tag, None)
+        rec["primary"] = primary_record(acc, 2, None)
         return rec
     work = count_work(triangles, width, height, spp, "auto")
     ref_visits = None
@@ -395,6 +417,7 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
         rec["cpu_baseline"] = base
         rec["gpu_over_cpu"] = value / base["value"]
     rec["roofline"] = roofline(acc, 2, work, tag, ref_visits)
+    rec["primary"] = primary_record(acc, 2, work)
     return rec
 
 
@@ -528,6 +551,7 @@ def main():
             out["cpu_baseline"] = base
             out["config"]["gpu_over_cpu"] = value / base["value"]
             out["roofline"] = roofline(acc, args.steps, work, workload_tag("soup", args.triangles, W, H, args.depth), ref_visits)
+            out["primary"] = primary_record(acc, args.steps, work)
             if not args.no_secondary and (args.triangles, W, H, args.spp) == (100000, 1280, 720, 256):
                 sec = []
                 sec.append(secondary_record(xpu, scenes, "Soup(1000000, seed 1234) 1280x720 256 spp depth 9 (north star's target scene)",
@@ -546,8 +570,7 @@ def main():
             out["roofline"] = roofline(acc, args.steps, None, workload_tag("soup", args.triangles, W, H, args.depth), None) if world == 1 else {
                 "bound": None, "kernel": "k_trace", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "note": "roofline and cpu_baseline are reported at N = 1"}
-        out["config"]["kernel_ms_per_step"] = {"trace": acc["closest_ms"] / args.steps, "shade": acc["shade_kernel_ms"] / args.steps,
-                                               "begin_pass_film": (acc["shade_ms"] - acc["shade_kernel_ms"]) / args.steps, "frame": acc["frame_ms"] / args.steps}
+        out["config"]["kernel_ms_per_step"] = {**kernel_ms(acc, args.steps), "frame": acc["frame_ms"] / args.steps}
         print(json.dumps(out))
     else:
         dev.close()

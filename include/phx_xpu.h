@@ -223,6 +223,14 @@ typedef struct phx_stats {
   double   shade_kernel_ms;    /* of shade_ms: the shade/NEE/integrate launches alone (k_shade or k_shade_g), HIP events */
   uint64_t shade_launches;     /* how many of them */
   uint64_t shade_general;      /* 1: the scene has non-Lambert closures and runs k_shade_g; 0: k_shade (Lambert only) */
+  double   primary_ms;         /* of trace_ms: the camera-ray launches (k_trace_primary: one packet walk per 64 rays), HIP events; closest_ms
+                                  holds the k_trace launches alone */
+  uint64_t primary_launches;   /* how many of them (one per pass) */
+  uint64_t primary_packets;    /* instrumented: packets of 64 camera rays walked by k_trace_primary ... */
+  uint64_t primary_fallbacks;  /* ... of which this many had rays in more than one direction octant and took the per-lane walk */
+  uint64_t primary_node_tests; /* instrumented: node tests per packet (one test serves its 64 rays), summed */
+  uint64_t primary_tri_tests;  /* instrumented: triangles a packet reached (each is tested by its 64 lanes), summed */
+  uint64_t primary_tri_lanes_hit; /* instrumented: lanes whose closest hit a triangle test improved, summed */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

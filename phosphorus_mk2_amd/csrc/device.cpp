@@ -655,15 +655,18 @@ int phx_device::run_frame() {
   stats.wave_iters = ds.wave_iters; stats.node_block_execs = ds.node_block_execs; stats.tri_block_execs = ds.tri_block_execs; stats.refills = ds.refills;
   stats.idle_lane_iters = ds.idle_lane_iters; stats.tri_pending_lane_iters = ds.tri_pending_lane_iters;
   for (int k = 0; k < 8; ++k) stats.stack_pushes[k] = ds.stack_pushes[k];
+  stats.primary_packets = ds.primary_packets; stats.primary_fallbacks = ds.primary_fallbacks; stats.primary_node_tests = ds.primary_node_tests;
+  stats.primary_tri_tests = ds.primary_tri_tests; stats.primary_tri_lanes_hit = ds.primary_tri_lanes_hit;
   if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace: " + std::to_string(ds.watchdog) + " wave(s) hit the iteration watchdog: the frame is incomplete");
   for (auto& te : timed) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));
     if (te.second == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
+    else if (te.second == 4) { stats.primary_ms += ms; stats.primary_launches++; }  // k_trace_primary: the camera rays of a pass
     else stats.shade_ms += ms;
     if (te.second == 3) { stats.shade_kernel_ms += ms; stats.shade_launches++; }
   }
-  stats.trace_ms = stats.closest_ms + stats.shadow_ms;
+  stats.trace_ms = stats.closest_ms + stats.shadow_ms + stats.primary_ms;
   stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return PHX_OK;
 }
@@ -756,11 +759,13 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
       // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
       const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
-      if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, bounce > 0, cap, bounce == 0, s0); }))) return rc;
+      if (bounce == 0) {  // the camera rays: one packet walk per 64 x n of them
+        if ((rc = timed_launch(4, [&]() { launch_trace_primary(stream, scene, B, cap, s0, q, sq_read); }))) return rc;
+      } else if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, 1, cap); }))) return rc;
       if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
       q ^= 1;
     }
-    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap, 0, s0); }))) return rc;
+    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;
     if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
     HIPCHK(hipGetLastError());
   }

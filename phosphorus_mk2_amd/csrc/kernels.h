@@ -48,7 +48,7 @@ struct DevScene {
   uint32_t num_cus;               // compute units of the device (persistent grid sizing)
   uint32_t diffuse_only;          // 1: every lobe of every material is Lambert (k_shade<1>); 2: and no material has more than one (k_shade<2>)
   uint32_t any_per_hit;           // some material's closure weights depend on the hit (glass): k_shade<0>; none: k_shade<3>
-  uint2* stack_spill;             // k_trace<.,.,.,SPILL>: stack entries below the levels kept in LDS, [level - lds_levels][thread of the grid]
+  uint2* stack_spill;             // k_trace<., SPILL>: stack entries below the levels kept in LDS, [level - lds_levels][thread of the grid]
   uint32_t spill_stride;          // threads of the largest k_trace grid (0 = every level is in LDS)
 };
 
@@ -63,6 +63,9 @@ struct DevStats {
   // wave-level: loop iterations, executions of the node block / the triangle block (a block runs when ANY lane needs it)
   unsigned long long wave_iters, node_block_execs, tri_block_execs, refills;
   unsigned long long idle_lane_iters, tri_pending_lane_iters;
+  // k_trace_primary (instrumented build): packets walked, packets that fell back to the per-lane walk, node tests and triangle tests
+  // per PACKET (one test serves the 64 rays), and lanes whose ray was improved by a triangle test (of 64 per test)
+  unsigned long long primary_packets, primary_fallbacks, primary_node_tests, primary_tri_tests, primary_tri_lanes_hit;
   unsigned long long watchdog;         // k_trace waves that gave up after PHX_TRACE_WATCHDOG iterations: 0, or the frame is reported as failed
   unsigned long long stack_pushes[8];  // instrumented: pushes onto the per-lane group stack by the depth they land at (7 = 7 and deeper)  // instrumented: lanes without a ray / with triangles still pending at the node block, summed over iterations
 };
@@ -97,8 +100,10 @@ bool launch_counts_traversal_work();  // true in the instrumented build (PHX_COU
 // start of a pass: queue 0 stands for the num_pixels x num_samples camera rays, which are rebuilt on the fly (camera_ray)
 void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples);
 // one persistent launch: closest-hit rays of queue q (do_closest) + any-hit rays of shadow queue sq (do_shadow)
-void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
-                  int camera_rays, uint32_t sample0);
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity);
+// step 0 of a pass: the npaths camera rays (never stored: rebuilt from the pixel and jitter tables), walked as packets by k_trace_primary;
+// writes the hit records of queue q and does k_trace's start-of-step bookkeeping
+void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t npaths, uint32_t sample0, int q, int sq);
 // shades queue q, appends survivors to queue q^1 and NEE rays to shadow queue sq
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays);
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);

@@ -2,7 +2,9 @@
 // HBM layout).  One ray / path per lane, 64-lane wavefronts.
 //
 //   camera_ray  camera::perspective_kernel_t (reference src/kernels/cpu/camera.hpp:80-159) + spt::state_t::reset: a device
-//               function — primary rays are rebuilt on the fly by the first k_trace / k_shade of a pass, never stored
+//               function — primary rays are rebuilt on the fly by k_trace_primary and the first k_shade of a pass, never stored
+//   k_trace_primary  the same trace for the camera rays of a pass, the one coherent launch of a frame: a wave walks the tree once
+//               for a packet of 64..256 rays (interval slab test per node, the reference's triangle test per ray)
 //   k_trace     stream_mbvh_kernel_t::trace (src/kernels/cpu/stream_bvh_kernel.cpp:18-161) re-thought per lane:
 //               BVH8 nodelets, (base,mask) group stack in LDS, closest-hit and any-hit rays in one persistent launch,
 //               lanes refilled from chunks each wave pulls for itself
@@ -71,14 +73,7 @@ __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, 
 // camera::perspective_kernel_t (kernels/cpu/camera.hpp:80-159), pinhole.  Primary rays are never stored: the first
 // k_trace of a pass and the first k_shade both rebuild the ray of path `path` from the pixel table and the jitter table
 // (about 40 instructions) instead of writing and re-reading 32 B per path.
-#ifndef PHX_PROBE_SCRAMBLE
-#define PHX_PROBE_SCRAMBLE 0  /* coherence probe (never in the product build; the film is scrambled): the camera ray of path i is that of
-                                 path (i * 1000003) mod n - the same set of rays, traced in an order without any coherence */
-#endif
 __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers& pb, uint32_t path, uint32_t sample0, v3& p, v3& w) {
-#if PHX_PROBE_SCRAMBLE
-  path = (uint32_t)(((unsigned long long)path * 1000003ull) % ((unsigned long long)pb.num_pixels * pb.num_samples));
-#endif
   const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;  // pixel-major: a wave = 64 samples of one pixel
   const uint32_t xy = pb.pix_xy[pix];
   const float sx = (float)(xy & 0xffffu), sy = (float)(xy >> 16);
@@ -167,11 +162,11 @@ struct DynQueue {            // the launch is persistent and every WAVE pulls ch
   uint32_t num_waves;
   uint32_t* cursor;          // pb.counters + CNT_CURSOR: two global cursors, zeroed by the kernel that filled the queues
 };
-template <int BLOCK, bool GEN /* the closest-hit queue is the camera rays of this pass */, bool SPILL /* the stack's deep levels live in HBM */>
+template <int BLOCK, bool SPILL /* the stack's deep levels live in HBM */>
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q,
                                              uint32_t* cursor /* LDS: the workgroup's ranges */, uint2* stack_base, uint32_t lds_levels,
                                              uint2* spill_base /* this thread's column of sc.stack_spill */, uint32_t refill_min,
-                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop, uint32_t sample0,
+                                             const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop,
                                              const DynQueue dq, const uint8_t* __restrict__ perm_lut) {
   const uint32_t lane = __lane_id();
   bool active = false, any = false;
@@ -250,12 +245,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         const uint32_t l5 = lane & 31u, below = (1u << l5) - 1u, ilo = (uint32_t)idle, ihi = (uint32_t)(idle >> 32);
         const uint32_t my = base + (uint32_t)__popc(ilo & below) + (uint32_t)__popc(ihi & below) + (lane >= 32u ? ((ilo >> l5) & 1u) : 0u);
         if (my < hi) {
-          if (GEN && phase == 1u) {
-            v3 co, cd;
-            camera_ray(sc, pb, my, sample0, co, cd);
-            r = make_ray_ctx(co, cd);
-            tbest = FLT_MAX; path = my;
-          } else {
+          {
             float4 a, b;
             if (phase == 0u) { a = pb.so[my]; b = pb.sd[my]; } else { a = ro[my]; b = rd[my]; }
             r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
@@ -415,9 +405,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 //   with per-wave global chunks 512 rays were the optimum, 64-ray chunks were atomic-bound).  A wave
 //   drains once per launch, not once per slice, and a slow image region is shared by everyone.
 // Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][8 cursor words][2 KB octant table].
-template <int BLOCK, bool GEN, bool SPILL = false>
+template <int BLOCK, bool SPILL = false>
 __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
-                                                 uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t sample0, uint32_t target_chunks) {
+                                                 uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
@@ -459,8 +449,8 @@ __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb,
   for (uint32_t i = threadIdx.x; i < 2048u; i += BLOCK) perm_lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
 #endif
   __syncthreads();
-  trace_stream<BLOCK, GEN, SPILL>(sc, pb, q, cursor, stack + threadIdx.x, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
-                                  refill_min, top, ntop, sample0, dq, perm_lut);
+  trace_stream<BLOCK, SPILL>(sc, pb, q, cursor, stack + threadIdx.x, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
+                                  refill_min, top, ntop, dq, perm_lut);
 }
 
 // stage-level hook (phx_dev_trace): one ray per lane run to completion with the plain traverse8 loop of bvh8.h.  The per-lane
@@ -475,6 +465,200 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_trace_rays(DevScene sc, uint32_t 
   Hit h;
   traverse8<ANY>(sc.pool, sc.grid, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), b.w, h, st);
   hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri == 0xffffffffu ? 0xffffffffu : sc.tris[h.tri].prim));  // primitive in scene_t::triangles() order
+}
+
+// ---- primary rays as packets ---------------------------------------------------------------------------------------------------
+// The camera rays of a pass are the one coherent launch of a frame: path ids are pixel-major, so the 64 rays of a wave are 64
+// samples of ONE pixel (or of a few neighbouring ones when a pass holds fewer than 64 samples per pixel) and walk the same nodes.
+// k_trace runs them like any other rays — every lane tests all eight child boxes of every node it visits, ~290 VALU instructions
+// per visit, and the launch sits at the ALU cost of that: 12.9 ms of the 72 ms bench frame.  Here a wave walks the tree ONCE for
+// its 64 rays: a node is tested against the packet's interval of origins and reciprocal directions — eight lanes, one child box
+// each, interval arithmetic on the same slab test — and every lane runs the reference's triangle test on each triangle the packet
+// reaches.  The packet test passes whenever some lane's own test would (a product of two intervals contains every lane's product,
+// rounding included, because rounding is monotonic), so the lanes meet a superset of the triangles they meet in k_trace, and
+// the closest hit with its lowest-primitive tie rule does not depend on which superset (bvh8.h).  A wave whose rays do not share a
+// direction octant (a pixel on one of the film's axes) falls back to the per-lane walk of bvh8.h.
+// wave-wide min / max through DPP (four shifts inside the rows of 16, two row broadcasts; the result lands in lane 63): 13 instructions,
+// where six __shfl_xor rounds would be twelve trips through the LDS crossbar
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce_f(float x) {
+#define PHX_DPP_STEP(ctrl, rows) { const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), ctrl, rows, 0xf, false)); x = MAX ? fmaxf(x, t) : fminf(x, t); }
+  PHX_DPP_STEP(0x111, 0xf) PHX_DPP_STEP(0x112, 0xf) PHX_DPP_STEP(0x114, 0xf) PHX_DPP_STEP(0x118, 0xf)  // row_shr:1, 2, 4, 8
+  PHX_DPP_STEP(0x142, 0xa) PHX_DPP_STEP(0x143, 0xc)                                                      // row_bcast:15 -> rows 1, 3; row_bcast:31 -> rows 2, 3
+#undef PHX_DPP_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ float wave_min_f(float x) { return wave_reduce_f<false>(x); }
+__device__ __forceinline__ float wave_max_f(float x) { return wave_reduce_f<true>(x); }
+// What a node test needs of the packet, per axis (wave-uniform).  With s = +1 / -1 the common sign of the rays' direction on the axis,
+// a ray's slab distance to the plane at c is (s (c - o)) * |1/d|: both factors are monotonic in what varies over the packet, so
+//   entry  >=  fma(s, c_near, kn) * (that >= 0 ? bmin : bmax),   kn = -s * (the origin coordinate that makes s (c - o) smallest)
+//   exit   <=  fma(s, c_far,  kf) * (that >= 0 ? bmax : bmin),   kf = -s * (the one that makes it largest)
+// and, rounding being monotonic, the bounds hold for the rounded values every lane would compute from its own ray.
+struct PacketBounds { float s[3], kn[3], kf[3], bmin[3], bmax[3]; };
+__device__ __forceinline__ void packet_axis(PacketBounds& B, int a, float o_lo, float o_hi, float ia_lo, float ia_hi /* this lane's rays: origin and |1/d| ranges */,
+                                            bool down /* the rays run towards -axis */) {
+  const float omin = wave_min_f(o_lo), omax = wave_max_f(o_hi);
+  B.bmin[a] = wave_min_f(ia_lo); B.bmax[a] = wave_max_f(ia_hi);
+  B.s[a] = down ? -1.0f : 1.0f;
+  B.kn[a] = down ? omin : -omax;   // s = -1: s (c - o) = o - c is smallest at omin, and -s * omin = omin
+  B.kf[a] = down ? omax : -omin;
+}
+typedef unsigned int phx_u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) phx_u4* phx_const_u4p;  // "constant" address space: a wave-uniform address is read through the scalar cache
+// bit s of the result: child slot s of the node may be hit by some ray of the packet (every lane returns the same mask)
+__device__ __forceinline__ uint32_t packet_node_hit8(const uint32_t* w, const SceneGrid& g, const PacketBounds& B, uint32_t oct_inv, float tmax_wave, uint32_t& valid) {
+  float px, py, pz;
+  node_origin_decode(w[0], w[1], g, px, py, pz, valid);
+  const uint32_t e = w[2];
+  const float sx = u32_as_f32((e & 0xffu) << 23), sy = u32_as_f32(((e >> 8) & 0xffu) << 23), sz = u32_as_f32(((e >> 16) & 0xffu) << 23);
+  // lane j (mod 8) takes child slot j: byte j of each of the six 8-byte plane rows (one 64-bit shift each; a select between the two
+  // words of a row would be turned into an indexed read of w[], i.e. scratch memory)
+  const uint32_t sh = (__lane_id() & 7u) * 8u;
+  auto plane = [&](int row) { return (float)((uint32_t)((((unsigned long long)w[row + 1] << 32) | (unsigned long long)w[row]) >> sh) & 0xffu); };
+  const float lox = fmaf(plane(4), sx, px), hix = fmaf(plane(10), sx, px);
+  const float loy = fmaf(plane(6), sy, py), hiy = fmaf(plane(12), sy, py);
+  const float loz = fmaf(plane(8), sz, pz), hiz = fmaf(plane(14), sz, pz);
+  const bool nx = !(oct_inv & 4u), ny = !(oct_inv & 2u), nz = !(oct_inv & 1u);  // the packet's rays all run down this axis
+  const float anx = fmaf(B.s[0], nx ? hix : lox, B.kn[0]), afx = fmaf(B.s[0], nx ? lox : hix, B.kf[0]);
+  const float any_ = fmaf(B.s[1], ny ? hiy : loy, B.kn[1]), afy = fmaf(B.s[1], ny ? loy : hiy, B.kf[1]);
+  const float anz = fmaf(B.s[2], nz ? hiz : loz, B.kn[2]), afz = fmaf(B.s[2], nz ? loz : hiz, B.kf[2]);
+  const float tnx = anx * (anx >= 0.0f ? B.bmin[0] : B.bmax[0]), tfx = afx * (afx >= 0.0f ? B.bmax[0] : B.bmin[0]);
+  const float tny = any_ * (any_ >= 0.0f ? B.bmin[1] : B.bmax[1]), tfy = afy * (afy >= 0.0f ? B.bmax[1] : B.bmin[1]);
+  const float tnz = anz * (anz >= 0.0f ? B.bmin[2] : B.bmax[2]), tfz = afz * (afz >= 0.0f ? B.bmax[2] : B.bmin[2]);
+  float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);
+  const float pad = 1.52587890625e-05f;  // 2^-16 of the distance on both ends: the lanes' own tests (node_hit8) differ from this one by roundings
+  tn = tn - fabsf(tn) * pad; tf = tf + fabsf(tf) * pad;
+  const bool hit = tn <= tf && tf >= 0.0f && tn <= tmax_wave;
+  return (uint32_t)__ballot(hit) & 0xffu & valid;  // empty slots carry inverted boxes AND are masked out
+}
+
+#define PHX_PRIMARY_BLOCK 256
+// RPL rays per lane: a packet is 64 x RPL consecutive paths (ray k of lane l is path base + 64 k + l).  The node tests are per packet,
+// so they are shared by more rays; the host picks RPL so that a packet stays inside one pixel's samples (launch_trace_primary).
+template <int RPL>
+__global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_trace_primary(DevScene sc, PassBuffers pb, uint32_t npaths, uint32_t sample0, int q, int sq) {
+  extern __shared__ uint2 primary_lds[];  // [4 waves x PHX_MAX_BVH_DEPTH] one shared stack per wave, then [levels x 256] per-lane stacks of the fallback walk
+  uint2* lane_stacks = primary_lds + (PHX_PRIMARY_BLOCK / 64) * PHX_MAX_BVH_DEPTH;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // what k_trace does at the start of a step (no shadow rays yet in step 0)
+    pb.counters[(q ^ 1) * CNT_STRIDE] = 0; pb.counters[CNT_SHADOW + (sq ^ 1) * CNT_STRIDE] = 0;
+    atomicAdd(&pb.stats->rays_closest, (unsigned long long)npaths);
+  }
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+  const uint32_t base = (blockIdx.x * (PHX_PRIMARY_BLOCK / 64) + wave) * (64u * RPL);
+  if (base >= npaths) return;
+  uint32_t idx[RPL];
+  RayCtx r[RPL];
+  float tbest[RPL], hu[RPL], hv[RPL];
+  uint32_t htri[RPL], hprim[RPL];
+  bool mixed = false;
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    idx[k] = base + 64u * k + lane;
+    v3 co, cd;
+    camera_ray(sc, pb, min(idx[k], npaths - 1u), sample0, co, cd);  // rays past the end repeat the last one and write nothing
+    r[k] = make_ray_ctx(co, cd);
+    tbest[k] = FLT_MAX; hu[k] = 0.0f; hv[k] = 0.0f; htri[k] = 0xffffffffu; hprim[k] = 0;
+  }
+  const uint32_t oct = PHX_UNI(r[0].oct_inv);
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) mixed = mixed || r[k].oct_inv != oct;
+  if (__ballot(mixed) != 0ull) {
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      LdsStack<0> st{lane_stacks + threadIdx.x, 0};
+      Hit h;
+      traverse8<false>(sc.pool, sc.grid, r[k].o, r[k].d, FLT_MAX, h, st);
+      tbest[k] = h.t; hu[k] = h.u; hv[k] = h.v; htri[k] = h.tri;
+    }
+#if PHX_COUNT
+    if (lane == 0) { atomicAdd(&pb.stats->primary_packets, 1ull); atomicAdd(&pb.stats->primary_fallbacks, 1ull); }
+#endif
+  } else {
+    PacketBounds B;
+    {
+      v3 olo = r[0].o, ohi = r[0].o, ilo(fabsf(r[0].idx), fabsf(r[0].idy), fabsf(r[0].idz)), ihi = ilo;
+#pragma unroll
+      for (int k = 1; k < RPL; ++k) {
+        olo = v3(fminf(olo.x, r[k].o.x), fminf(olo.y, r[k].o.y), fminf(olo.z, r[k].o.z)); ohi = v3(fmaxf(ohi.x, r[k].o.x), fmaxf(ohi.y, r[k].o.y), fmaxf(ohi.z, r[k].o.z));
+        const v3 ia(fabsf(r[k].idx), fabsf(r[k].idy), fabsf(r[k].idz));
+        ilo = v3(fminf(ilo.x, ia.x), fminf(ilo.y, ia.y), fminf(ilo.z, ia.z)); ihi = v3(fmaxf(ihi.x, ia.x), fmaxf(ihi.y, ia.y), fmaxf(ihi.z, ia.z));
+      }
+      packet_axis(B, 0, olo.x, ohi.x, ilo.x, ihi.x, !(oct & 4u)); packet_axis(B, 1, olo.y, ohi.y, ilo.y, ihi.y, !(oct & 2u)); packet_axis(B, 2, olo.z, ohi.z, ilo.z, ihi.z, !(oct & 1u));
+    }
+    float tmax_wave = FLT_MAX;  // the farthest closest-hit distance of the packet so far
+    uint32_t ng_base = 0, ng_hits = 0x80000000u;  // the root as a one-child group (bvh8.h: traverse8)
+    uint32_t sp = 0, guard = 0;
+#if PHX_COUNT
+    uint32_t cnt_nodes = 0, cnt_tris = 0, cnt_lanes = 0;
+#endif
+    uint2* stack = primary_lds + wave * PHX_MAX_BVH_DEPTH;
+    for (;;) {
+      if (++guard > PHX_TRACE_WATCHDOG) { if (lane == 0) atomicAdd(&pb.stats->watchdog, 1ull); break; }
+      const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
+      const uint32_t rest = ng_hits & ~(1u << bit);
+      if (rest > 0x00ffffffu) { if (lane == 0) stack[sp] = make_uint2(ng_base, rest); ++sp; }
+      const uint32_t slot = (bit - 24u) ^ oct;
+      const uint32_t ni = PHX_UNI(ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot)));
+      uint32_t w[16];
+      {
+        const phx_const_u4p s4 = (phx_const_u4p)(sc.pool) + (size_t)ni * 4u;  // the pool is never written while a frame runs
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const phx_u4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+      }
+      uint32_t valid;
+#if PHX_COUNT
+      ++cnt_nodes;
+#endif
+      const uint32_t hit8 = packet_node_hit8(w, sc.grid, B, oct, tmax_wave, valid);
+      const uint32_t imask = w[2] >> 24;
+      ng_base = PHX_UNI(w[3]);
+      ng_hits = PHX_UNI((perm_xor8(hit8 & imask, oct) << 24) | valid);
+      uint32_t th = PHX_UNI(hit8 & ~imask);
+      while (th != 0u) {
+        const uint32_t k = 31u - (uint32_t)__clz((int)th);
+        th &= ~(1u << k);
+        const uint32_t ti = PHX_UNI(ng_base + (uint32_t)__popc(valid & ~(0xffffffffu << k)));
+        const phx_const_u4p t4 = (phx_const_u4p)(sc.pool) + (size_t)ti * 4u;
+        const phx_u4 t0 = t4[0], t1 = t4[1], t2 = t4[2];
+        TriRec T;
+        T.v0x = u2f(t0.x); T.v0y = u2f(t0.y); T.v0z = u2f(t0.z); T.e0x = u2f(t0.w);
+        T.e0y = u2f(t1.x); T.e0z = u2f(t1.y); T.e1x = u2f(t1.z); T.e1y = u2f(t1.w);
+        T.e1z = u2f(t2.x); T.prim = t2.y;
+        bool any_better = false;
+        float tworst = 0.0f;
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
+          float us, vs, ds;
+          const bool better = mt_intersect(T, r[m].o, r[m].d, tbest[m], hprim[m], us, vs, ds);
+          if (better) { tbest[m] = ds; hu[m] = us; hv[m] = vs; htri[m] = ti; hprim[m] = T.prim; }
+          any_better = any_better || better;
+          tworst = fmaxf(tworst, tbest[m]);
+        }
+#if PHX_COUNT
+        ++cnt_tris; cnt_lanes += (uint32_t)__popcll(__ballot(any_better));
+#endif
+        if (__ballot(any_better) != 0ull) tmax_wave = wave_max_f(tworst);
+      }
+      if (ng_hits <= 0x00ffffffu) {
+        if (sp == 0u) break;
+        --sp;
+        const uint2 e = stack[sp];
+        ng_base = PHX_UNI(e.x); ng_hits = PHX_UNI(e.y);
+      }
+    }
+#if PHX_COUNT
+    if (lane == 0) {
+      atomicAdd(&pb.stats->primary_packets, 1ull);
+      atomicAdd(&pb.stats->primary_node_tests, (unsigned long long)cnt_nodes);
+      atomicAdd(&pb.stats->primary_tri_tests, (unsigned long long)cnt_tris);
+      atomicAdd(&pb.stats->primary_tri_lanes_hit, (unsigned long long)cnt_lanes);
+    }
+#endif
+  }
+#pragma unroll
+  for (int k = 0; k < RPL; ++k)
+    if (idx[k] < npaths) pb.hit[idx[k]] = make_float4(tbest[k], hu[k], hv[k], u2f(htri[k]));
 }
 
 // ---- shade + next-event estimation + integrate ------------------------------------------------------
@@ -999,10 +1183,10 @@ const TraceEnv& trace_env() {
 }
 template <typename F>
 void for_each_trace_kernel(F&& f) {
-  f(reinterpret_cast<const void*>(&k_trace<256, true>)); f(reinterpret_cast<const void*>(&k_trace<512, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, true>));
-  f(reinterpret_cast<const void*>(&k_trace<256, false>)); f(reinterpret_cast<const void*>(&k_trace<512, false>)); f(reinterpret_cast<const void*>(&k_trace<1024, false>));
-  f(reinterpret_cast<const void*>(&k_trace<1024, true, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true>));
+  f(reinterpret_cast<const void*>(&k_trace<256>)); f(reinterpret_cast<const void*>(&k_trace<512>)); f(reinterpret_cast<const void*>(&k_trace<1024>));
+  f(reinterpret_cast<const void*>(&k_trace<1024, true>));
   f(reinterpret_cast<const void*>(&k_trace_rays<true>)); f(reinterpret_cast<const void*>(&k_trace_rays<false>));
+  f(reinterpret_cast<const void*>(&k_trace_primary<1>)); f(reinterpret_cast<const void*>(&k_trace_primary<2>)); f(reinterpret_cast<const void*>(&k_trace_primary<4>));
 }
 }  // namespace
 
@@ -1026,7 +1210,7 @@ TracePlan trace_plan(const DevScene& sc) {
   // stack entries needed = BVH depth - 1: one pending sibling group per level above the deepest node (the root "group" has a
   // single member and the deepest nodes have no inner children); tests/test_host_bvh8.py checks the bound
   P.levels = std::max(2u, sc.stack_levels > 1u ? sc.stack_levels - 1u : 1u);
-  // ... of which the top lds_levels live in LDS and the rest in HBM (k_trace<1024, ., true, SPILL>).  A lane's stack is rarely deep
+  // ... of which the top lds_levels live in LDS and the rest in HBM (k_trace<1024, SPILL>).  A lane's stack is rarely deep
   // (100 k triangles, 8 levels: 6.5 pushes per ray, 0.011 of them land at depth 5 or below; 1 M, 9 levels: 0.013 at depth 6 or
   // below), but the test on every push and pop costs what the freed LDS buys back on trees whose stacks fit (profiles/README.md):
   // spilling is for trees so deep that the stacks alone would force smaller workgroups and fewer resident waves.
@@ -1065,8 +1249,7 @@ TracePlan trace_plan(const DevScene& sc) {
   return P;
 }
 
-void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity,
-                  int camera_rays, uint32_t sample0) {
+void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, int do_closest, int do_shadow, uint32_t capacity) {
   const TraceEnv& E = trace_env();
   const TracePlan P = trace_plan(sc);
   const uint32_t block = P.block, ntop = P.ntop, lds = P.lds_bytes, levels = P.lds_levels;
@@ -1075,15 +1258,12 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   grid = std::max(8u, std::min(grid, need));
   const dim3 g(grid), b(block);
   auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, ntop, levels, E.min_chunks, sample0, E.target_chunks);
+    hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, ntop, levels, E.min_chunks, E.target_chunks);
   };
-  if (P.lds_levels < P.levels) {  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
-    if (camera_rays) go(&k_trace<1024, true, true>); else go(&k_trace<1024, false, true>);
-  } else if (camera_rays) {
-    if (block == 256) go(&k_trace<256, true>); else if (block == 512) go(&k_trace<512, true>); else go(&k_trace<1024, true>);
-  } else {
-    if (block == 256) go(&k_trace<256, false>); else if (block == 512) go(&k_trace<512, false>); else go(&k_trace<1024, false>);
-  }
+  if (P.lds_levels < P.levels) go(&k_trace<1024, true>);  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
+  else if (block == 256) go(&k_trace<256>);
+  else if (block == 512) go(&k_trace<512>);
+  else go(&k_trace<1024>);
 }
 // k_shade / k_shade_g walk the queue with a fixed grid: PHX_SHADE_GRID workgroups per resident slot (never more than the queue's
 // capacity needs)
@@ -1113,6 +1293,19 @@ void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
     if (camera_rays) hipLaunchKernelGGL((k_shade_g<false, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
     else hipLaunchKernelGGL((k_shade_g<false, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   }
+}
+void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t npaths, uint32_t sample0, int q, int sq) {
+  static const int rpl_env = [] { const char* v = getenv("PHX_PRIMARY_RPL"); return v ? atoi(v) : 0; }();  // experiment: 1, 2 or 4 rays per lane
+  const size_t lds = ((size_t)std::max(2u, std::min(sc.stack_levels, (uint32_t)PHX_MAX_BVH_DEPTH)) * PHX_PRIMARY_BLOCK + (PHX_PRIMARY_BLOCK / 64) * PHX_MAX_BVH_DEPTH) * sizeof(uint2);
+  // path ids are pixel-major (pixel * samples_of_this_pass + sample): 256 consecutive paths are samples of ONE pixel when the pass holds
+  // a multiple of 256 samples per pixel; otherwise 128 paths, i.e. the samples of a few pixels next to each other in a tile row
+  // (measured, profiles/r03_zo_primary_packets.log: 4 rays per lane beat 2 only inside one pixel; 2 beat 1 from 16 samples per pixel up)
+  uint32_t rpl = pb.num_samples % 256u == 0 ? 4u : pb.num_samples >= 16u ? 2u : 1u;
+  if (rpl_env == 1 || rpl_env == 2 || rpl_env == 4) rpl = (uint32_t)rpl_env;
+  const dim3 g((npaths + PHX_PRIMARY_BLOCK * rpl - 1) / (PHX_PRIMARY_BLOCK * rpl)), b(PHX_PRIMARY_BLOCK);
+  if (rpl == 4) hipLaunchKernelGGL(k_trace_primary<4>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
+  else if (rpl == 2) hipLaunchKernelGGL(k_trace_primary<2>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
+  else hipLaunchKernelGGL(k_trace_primary<1>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
   hipLaunchKernelGGL(k_film, dim3((pb.num_pixels + PHX_FILM_PIX - 1) / PHX_FILM_PIX), dim3(256), 0, stream, pb, num_samples, inv);

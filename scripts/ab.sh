@@ -24,7 +24,7 @@ for f in sorted(glob.glob("$OUT/*_*_*.json")):
     b=os.path.basename(f)[:-5]; name,tri,rep=b.rsplit("_",2)
     try: d=json.load(open(f))
     except Exception: continue
-    res[(name,tri)].append((d["value"], d["config"]["kernel_ms_per_step"]["trace"], d["config"]["kernel_ms_per_step"]["shade"]))
+    k=d["config"]["kernel_ms_per_step"]; res[(name,tri)].append((d["value"], k["trace"], k["shade"], k.get("primary", 0.0)))
 for (name,tri),v in sorted(res.items(), key=lambda x:(x[0][1],x[0][0])):
-    print(f"{tri:>8} {name:<16} " + "  ".join(f"{a:7.0f} Mrays/s trace {b:6.2f} ms shade {c:5.2f} ms" for a,b,c in v))
+    print(f"{tri:>8} {name:<16} " + "  ".join(f"{a:7.0f} Mrays/s primary {p:5.2f} trace {b:6.2f} shade {c:5.2f} ms" for a,b,c,p in v))
 PY

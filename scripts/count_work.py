@@ -16,11 +16,17 @@ film, st = xpu.render(sc, spp=a.spp, pps=1, depth=9, seed=1, native_sink=True, b
 assert st["instrumented"] == 1
 out = {"film_sha1": hashlib.sha1(film.tobytes()).hexdigest(), "triangles": a.triangles, "film": [a.width, a.height], "spp": a.spp, "builder": a.builder, "bvh_bytes": st["bvh_bytes"], "bvh_nodes": st["bvh_nodes"],
        "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]}}
+# camera rays are walked as packets by k_trace_primary (unless PHX_PRIMARY_PACKETS=0): they are not k_trace's work
+primary_rays = st["camera_samples"] if st["primary_launches"] else 0
+pk = max(1, st["primary_packets"] - st["primary_fallbacks"])
+out["primary"] = {"rays": primary_rays, "packets": st["primary_packets"], "fallback_packets": st["primary_fallbacks"],
+                  "node_tests_per_packet": st["primary_node_tests"] / pk, "tri_tests_per_packet": st["primary_tri_tests"] / pk,
+                  "lanes_improved_per_tri_test": st["primary_tri_lanes_hit"] / max(1, st["primary_tri_tests"])}
 for k, name in ((0, "closest"), (1, "shadow")):
-    rays = st["rays_closest"] if k == 0 else st["rays_shadow"]
+    rays = st["rays_closest"] - primary_rays if k == 0 else st["rays_shadow"]
     out[name] = {"rays": rays, "node_visits_lds_per_ray": st["node_visits_lds"][k] / rays, "node_visits_mem_per_ray": st["node_visits_mem"][k] / rays,
                  "tri_tests_per_ray": st["tri_tests"][k] / rays}
-rays = st["rays_closest"] + st["rays_shadow"]
+rays = st["rays_closest"] - primary_rays + st["rays_shadow"]
 nv = sum(st["node_visits_lds"]) + sum(st["node_visits_mem"]); tt = sum(st["tri_tests"])
 out["wave"] = {"iterations": st["wave_iters"], "node_block_execs": st["node_block_execs"], "tri_block_execs": st["tri_block_execs"], "refills": st["refills"], "idle_lanes_per_iteration": st["idle_lane_iters"] / max(1, st["wave_iters"]), "tri_pending_lanes_per_iteration": st["tri_pending_lane_iters"] / max(1, st["wave_iters"]),
                "lanes_per_node_block": nv / max(1, st["node_block_execs"]), "lanes_per_tri_block": tt / max(1, st["tri_block_execs"]),

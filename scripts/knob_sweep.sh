@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 run() { # label, env assignments...
   label=$1; shift
   for tri in 100000 1000000; do
-    env "$@" python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --triangles $tri 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$label'.ljust(24), '$tri'.rjust(8), round(d['value']), 'trace %.2f shade %.2f' % (d['config']['kernel_ms_per_step']['trace'], d['config']['kernel_ms_per_step']['shade_gen_film']))"
+    env "$@" python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --triangles $tri 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$label'.ljust(24), '$tri'.rjust(8), round(d['value']), 'trace %.2f shade %.2f' % (d['config']['kernel_ms_per_step']['trace'], d['config']['kernel_ms_per_step']['shade']))"
   done
 }
 run default PHX_NONE=0

@@ -29,7 +29,7 @@ stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
-# per k_trace launch: counters keyed by the launch's position among the k_trace dispatches of its pass (0 = camera rays, 1.. = bounces)
+# per k_trace launch: counters keyed by the launch's position among the k_trace dispatches of its pass (0 = the first bounce: the camera rays are k_trace_primary's)
 per_launch = collections.defaultdict(lambda: collections.defaultdict(list))
 launches = collections.defaultdict(set)
 passes = collections.defaultdict(set)  # a counter collected in several passes is averaged over them

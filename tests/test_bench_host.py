@@ -61,6 +61,25 @@ def test_roofline_fraction_is_work_based_and_diagnostics_use_their_own_capture()
     assert a["traffic"] == k["hbm_bytes_per_launch_corrected"] and "GBps" in a["algorithmic_ref_layout"] and a["device_layout"]["bytes_per_ray"]["closest"] > 48
 
 
+def test_camera_rays_are_not_k_traces_work():
+    """k_trace_primary walks the camera rays: the k_trace roofline counts neither their number nor their time, and the record of the
+    primary kernel carries its own HIP-event time and the packet statistics of the instrumented build"""
+    import bench
+    work = {k: {"rays": r, "node_visits_lds_per_ray": 6.4, "node_visits_mem_per_ray": 13.5, "tri_tests_per_ray": 7.0} for k, r in (("closest", 205_000_000), ("shadow", 123_000_000))}
+    work["wave"] = {"lanes_per_node_block": 50.0, "lanes_per_tri_block": 18.0}
+    work["primary"] = {"rays": 236_000_000, "packets": 921_600, "fallback_packets": 2000, "node_tests_per_packet": 9.5, "tri_tests_per_packet": 3.7, "lanes_improved_per_tri_test": 12.0}
+    acc = bench.new_acc()
+    acc.update({"closest": 441_000_000, "shadow": 123_000_000, "camera": 236_000_000, "primary_rays": 236_000_000, "primary_ms": 3.7, "primary_launches": 1,
+                "closest_ms": 47.0, "shade_ms": 12.0, "shade_kernel_ms": 11.0, "launches": 9, "frame_ms": 63.5})
+    r = bench.roofline(acc, 1, work, None, None)
+    assert abs(r["kernel_rays_per_s"] - (205e6 + 123e6) / 0.047) < 1.0 and abs(r["rays_per_launch"] - 328e6 / 9) < 1.0
+    assert abs(r["frac"] - r["work"]["min_alu_ms_per_frame"] / 47.0) < 1e-9
+    p = bench.primary_record(acc, 1, work)
+    assert p["kernel"] == "k_trace_primary" and abs(p["rays_per_s"] - 236e6 / 3.7e-3) < 1.0 and p["packets"]["node_tests_per_packet"] == 9.5
+    assert bench.kernel_ms(acc, 1) == {"primary": 3.7, "trace": 47.0, "shade": 11.0, "begin_pass_film": 1.0}
+    assert bench.primary_record(bench.new_acc(), 1, None) is None
+
+
 def test_shade_roofline_counts_algorithmic_bytes_per_entry():
     import bench
     acc = bench.new_acc()
@@ -97,5 +116,10 @@ def test_newest_committed_bench_record_keeps_the_contract():
         assert all(0 < rf["diagnostics"][k]["frac"] <= 1 for k in ("valu_issue", "vector_l1", "l2", "hbm"))
         assert d["value_hbm_film"] == d["value"] and 0 < d["value_host_film"] < 1.05 * d["value"]
         assert len(d["secondary"]) == 4 and [s["roofline"]["kernel"] for s in d["secondary"]] == ["k_trace", "k_trace", "k_shade_g", "k_shade_g"]
+        if "primary" in d:  # r03_zq on: the camera rays have their own kernel, k_trace's roofline is about the other rays
+            pr = d["primary"]
+            assert pr["kernel"] == "k_trace_primary" and pr["rays_per_step"] == d["config"]["camera_samples_per_step"] and pr["ms_per_step"] > 0
+            assert abs(d["config"]["kernel_ms_per_step"]["primary"] - pr["ms_per_step"]) < 1e-9 and pr["packets"]["fallback_packets"] < 0.01 * pr["packets"]["packets"]
+            assert abs(rf["kernel_rays_per_s"] - (d["config"]["rays_per_step"] - pr["rays_per_step"]) / (rf["work"]["k_trace_ms_per_frame"] * 1e-3)) < 1e-6 * rf["kernel_rays_per_s"]
     else:
         assert all(0 < c["frac"] <= 1 for c in rf["ceilings"].values()) and rf["bound"] in rf["ceilings"] and len(d["secondary"]) == 2

@@ -120,6 +120,21 @@ def test_render_cornell_matches_oracle(xpu, orc):
     assert film[..., :3].max() > 0.1 and np.isfinite(film).all()
 
 
+@pytest.mark.parametrize("spp,flight", [(1, 0), (3, 0), (16, 0), (48, 0), (256, 0), (96, 32), (40, 16)])
+def test_camera_ray_packets_of_every_shape_match_oracle(xpu, orc, spp, flight):
+    """k_trace_primary walks the camera rays of a pass as packets of 64 / 128 / 256 consecutive paths (1, 2 or 4 rays per lane, by the
+    samples per pixel of the pass); a packet may be the samples of one pixel, span several pixels of a tile row, straddle two tiles,
+    end in the middle of a wave, or hold rays of several direction octants (the camera looks down -z: the pixels on the film's axes),
+    which sends it down the per-lane walk.  Every shape must give the oracle's film bit for bit, a ragged film included."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(3000, width=72, height=40)  # 32-pixel tiles: ragged on both axes
+    kw = {"samples_in_flight": flight} if flight else {}
+    film, st, (ref, ost) = _render_both(xpu, orc, sc, spp=spp, seed=11, **kw)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+    assert st["primary_launches"] == (1 if not flight else -(-spp // flight)) and st["primary_ms"] > 0
+    assert bits_equal(film[..., :3], ref[..., :3])
+
+
 @pytest.mark.parametrize("depth,pps,components", [(1, 1, 4), (2, 3, 4), (4, 1, 3)])
 def test_depth_pps_and_channel_options_match_oracle(xpu, orc, depth, pps, components):
     """parsed_options_t: path_depth (spt.hpp:314 a path takes at most `depth` steps), paths_per_sample (only the 1/(spp*pps)
@@ -630,7 +645,9 @@ def test_instrumented_build_counts_the_same_frame(xpu, tmp_path):
     film, st = xpu.render(scenes.soup(20000, width=320, height=192), spp=16, seed=1)
     assert hashlib.sha1(film.tobytes()).hexdigest() == w["film_sha1"]  # same film, bit for bit
     assert st["instrumented"] == 0 and st["node_visits_mem"] == [0, 0]  # the product library counts nothing
-    assert w["closest"]["rays"] == st["rays_closest"] and w["shadow"]["rays"] == st["rays_shadow"]
+    assert w["closest"]["rays"] + w["primary"]["rays"] == st["rays_closest"] and w["shadow"]["rays"] == st["rays_shadow"]
+    assert w["primary"]["rays"] == st["camera_samples"] and w["primary"]["rays"] <= w["primary"]["packets"] * 256 < 8 * w["primary"]["rays"]  # camera rays: k_trace_primary, 64 / 128 / 256 per packet
+    assert 1.0 <= w["primary"]["node_tests_per_packet"] < 1000 and w["primary"]["fallback_packets"] < 0.05 * w["primary"]["packets"]
     for k in ("closest", "shadow"):
         assert w[k]["node_visits_lds_per_ray"] >= 1.0  # the root is staged in LDS
         assert 1.0 <= w[k]["node_visits_lds_per_ray"] + w[k]["node_visits_mem_per_ray"] < 100 and 0 < w[k]["tri_tests_per_ray"] < 100
