@@ -463,20 +463,32 @@ def main():
         film_dev = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
     else:
         film_host = xpu.Film(W, H, 4)
+    # N > 1: two films, used in turn, so that the reduce of frame k (RCCL's stream) runs beside the rendering of frame k + 1 (the
+    # device's stream); pending[b] = the reduce still reading film b
+    films = [film_dev, torch.zeros_like(film_dev)] if use_dist else [film_dev]
+    pending = [None, None]
+    frame_no = [0]
 
     def barrier():
         if use_dist:
+            for b in (0, 1):  # every film reduce in flight belongs to the frames before the barrier
+                if pending[b] is not None:
+                    pending[b].wait(); pending[b] = None
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
         tiles.reset()
         if use_dist:
-            film_dev.zero_()
-            torch.cuda.synchronize()
-            dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
-            dev.join()  # join() synchronises the device's stream
-            pdist.reduce_film(film_dev, dst=0)  # the single film collective (RCCL over xGMI)
+            b = frame_no[0] & 1; frame_no[0] += 1
+            film = films[b]
+            if pending[b] is not None:
+                pending[b].wait()  # the reduce of two frames ago has read this film (orders torch's stream behind it)
+            film.zero_()
+            cleared = torch.cuda.Event(); cleared.record(); cleared.synchronize()  # the device renders on its own stream: wait for the zeros only
+            dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film.data_ptr()))
+            dev.join()  # join() synchronises the device's stream: the film is complete
+            pending[b] = pdist.reduce_film(film, dst=0, async_op=True)  # the single film collective (RCCL over xGMI), overlapped with the next frame
         elif film_dev is not None:
             # no clearing: at world 1 the device's tiles cover (and overwrite) every pixel of the film
             dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
@@ -526,6 +538,8 @@ def main():
         rays_total = float(rays_local)
 
     if rank == 0:
+        if use_dist:
+            film_dev = films[(frame_no[0] - 1) & 1]  # the film of the last frame, reduced onto this rank
         film = film_dev.cpu().numpy() if film_dev is not None else film_host.data
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_total / elapsed / 1e6
@@ -537,7 +551,7 @@ def main():
             "value_host_film": value if film_dev is None else value_other, "value_hbm_film": value_other if film_dev is None else value,
             "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "
                                    "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
-                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0" if use_dist else "none",
+                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0, overlapped with the next frame's rendering (two films)" if use_dist else "none",
                        "rays_per_step": rays_total / args.steps, "camera_samples_per_step": W * H * args.spp,
                        "preprocess_s": preprocess_s, "bvh_builder": args.bvh_builder, "bvh_build_ms": st["bvh_build_ms"],
                        "bvh_bytes": st["bvh_bytes"], "paths_in_flight": st["paths_in_flight"],

@@ -42,11 +42,12 @@ def init_process_group(backend, rank, world, device=None):
     return dist
 
 
-def reduce_film(film, dst=0):
-    """The single collective of a frame: sum the per-rank films onto rank `dst` (in place)."""
+def reduce_film(film, dst=0, async_op=False):
+    """The single collective of a frame: sum the per-rank films onto rank `dst` (in place).  async_op: returns the work handle instead
+    of the film — wait() on it before the film is read or cleared (bench.py overlaps the reduce with the next frame's rendering)."""
     import torch.distributed as dist
-    dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
-    return film
+    work = dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)
+    return work if async_op else film
 
 
 def max_over_ranks(value, device="cpu"):
