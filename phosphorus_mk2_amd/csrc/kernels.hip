@@ -534,10 +534,13 @@ __device__ __forceinline__ uint32_t packet_node_hit8(const uint32_t* w, const Sc
 }
 
 #define PHX_PRIMARY_BLOCK 256
+#ifndef PHX_PRIMARY_WAVES
+#define PHX_PRIMARY_WAVES 5  /* waves per SIMD the register allocator leaves room for: 95 VGPRs with 4 rays per lane (4: 98; 6: 80 + 48 B of scratch); 3.65 -> 3.35 ms */
+#endif
 // RPL rays per lane: a packet is 64 x RPL consecutive paths (ray k of lane l is path base + 64 k + l).  The node tests are per packet,
 // so they are shared by more rays; the host picks RPL so that a packet stays inside one pixel's samples (launch_trace_primary).
 template <int RPL>
-__global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_trace_primary(DevScene sc, PassBuffers pb, uint32_t npaths, uint32_t sample0, int q, int sq) {
+__global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves_per_eu(PHX_PRIMARY_WAVES, 8))) k_trace_primary(DevScene sc, PassBuffers pb, uint32_t npaths, uint32_t sample0, int q, int sq) {
   extern __shared__ uint2 primary_lds[];  // [4 waves x PHX_MAX_BVH_DEPTH] one shared stack per wave, then [levels x 256] per-lane stacks of the fallback walk
   uint2* lane_stacks = primary_lds + (PHX_PRIMARY_BLOCK / 64) * PHX_MAX_BVH_DEPTH;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // what k_trace does at the start of a step (no shadow rays yet in step 0)
