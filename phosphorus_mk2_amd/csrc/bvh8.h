@@ -182,6 +182,9 @@ typedef float phx_f2 __attribute__((ext_vector_type(2)));
 #ifndef PHX_SIGN_ACCUM
 #define PHX_SIGN_ACCUM 1
 #endif
+#ifndef PHX_NO_NEG_ZERO
+#define PHX_NO_NEG_ZERO 1
+#endif
 #ifndef PHX_PAD_FMA
 #define PHX_PAD_FMA 1  /* the padded exit distance minus the entry distance as ONE fma (one instruction less per child; -0.3 ms of 47: profiles/r03_zz_pad_fma_ab.log) */
 #endif
@@ -236,6 +239,14 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
   // ends at bit j.  tf + 0 turns an exit distance of -0 into +0 (t = -0 is a valid Moeller-Trumbore distance).
   uint32_t miss = 0;
   const float tmaxp = tmax * pad_far;
+#if PHX_NO_NEG_ZERO
+  // b + 0 is never -0, and then no plane distance fma(q, a, b) is (q a = -0 meets b = +0; exact cancellation gives +0): the exit
+  // distance needs no "+ 0" per child to keep t = -0 from reading as a miss (three adds per node instead of eight)
+  const float bx0 = bx + 0.0f, by0 = by + 0.0f, bz0 = bz + 0.0f;
+#define bx bx0
+#define by by0
+#define bz bz0
+#endif
 #pragma unroll
   for (int half = 1; half >= 0; --half) {
     const uint32_t nearx = nx ? w[10 + half] : w[4 + half], farx = nx ? w[4 + half] : w[10 + half];
@@ -252,7 +263,9 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
       const float tfz = fmaf((float)((farz >> sh) & 0xffu), az, bz);
       const float tn = fmaxf(fmaxf(tnx, tny), tnz);
       const float tf = fminf(fminf(tfx, tfy), tfz);
-#if PHX_PAD_FMA
+#if PHX_PAD_FMA && PHX_NO_NEG_ZERO
+      const uint32_t m = __float_as_uint(fmaf(tf, pad_far, -tn)) | __float_as_uint(tmaxp - tn) | __float_as_uint(tf);
+#elif PHX_PAD_FMA
       const uint32_t m = __float_as_uint(fmaf(tf, pad_far, -tn)) | __float_as_uint(tmaxp - tn) | __float_as_uint(tf + 0.0f);  // tf * pad - tn in one instruction
 #else
       const uint32_t m = __float_as_uint(tf * pad_far - tn) | __float_as_uint(tmaxp - tn) | __float_as_uint(tf + 0.0f);
@@ -261,6 +274,11 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
     }
   }
   hit8 = ~miss & 0xffu;
+#if PHX_NO_NEG_ZERO
+#undef bx
+#undef by
+#undef bz
+#endif
 #else
 #if PHX_USE_PK
   const phx_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
