@@ -474,10 +474,13 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_trace_rays(DevScene sc, uint32_t 
 // per visit, and the launch sits at the ALU cost of that: 12.9 ms of the 72 ms bench frame.  Here a wave walks the tree ONCE for
 // its 64 rays: a node is tested against the packet's interval of origins and reciprocal directions — eight lanes, one child box
 // each, interval arithmetic on the same slab test — and every lane runs the reference's triangle test on each triangle the packet
-// reaches.  The packet test passes whenever some lane's own test would (a product of two intervals contains every lane's product,
-// rounding included, because rounding is monotonic), so the lanes meet a superset of the triangles they meet in k_trace, and
-// the closest hit with its lowest-primitive tie rule does not depend on which superset (bvh8.h).  A wave whose rays do not share a
-// direction octant (a pixel on one of the film's axes) falls back to the per-lane walk of bvh8.h.
+// reaches.  The packet's bounds contain what every lane would get from the same expression with its own ray (a product of two intervals
+// contains every member's product, rounding included, because rounding is monotonic); k_trace's node_hit8 evaluates the slab
+// distances in another order, so the two differ by roundings, which 2^-16 of the distance on both ends is there to cover (node_hit8
+// itself pads by 2^-20).  The lanes then meet a superset of the triangles they meet in k_trace, and the closest hit with its
+// lowest-primitive tie rule does not depend on which superset (bvh8.h); that the films are identical bit for bit is tested, not assumed
+// (DESIGN.md section 4).  A wave whose rays do not share a direction octant (a pixel on one of the film's axes) falls back to the
+// per-lane walk of bvh8.h.
 // wave-wide min / max through DPP (four shifts inside the rows of 16, two row broadcasts; the result lands in lane 63): 13 instructions,
 // where six __shfl_xor rounds would be twelve trips through the LDS crossbar
 template <bool MAX>
