@@ -857,9 +857,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 // repo).  What changed, and why:
 //   * no per-hit copy of the material.  A glass hit used to resolve its closure weights into a private 576-byte DevMaterial (scratch
 //     memory, and every material read a flat load); now bsdf_f / bsdf_sample resolve a lobe's weight where they use it (bsdf.h).
-//   * the two halves of a step no longer overlap in registers: the NEE ray is appended to the shadow queue BEFORE roulette and BSDF
-//     sampling start, so its origin / direction / beta*Li are dead by then (the seam the reference has between light_sampler_t and
-//     integrator_t, spt.hpp:95-149 / 161-328); the hit's tangent frame is built once and used by both.
+//   * the two halves of a step (light_sampler_t and integrator_t, spt.hpp:95-149 / 161-328) share the hit's tangent frame, built once.
+//     (For most of round 3 the NEE ray was appended to its queue BEFORE roulette and BSDF sampling started, so that its ten registers
+//     were dead by then; once the kernel stood at 4 waves per SIMD whatever it did, one append for both queues per round won.)
 //   * a workgroup sorts a WINDOW of BLOCK x ITEMS hits by material, not BLOCK: with 16 recipes assigned round-robin a 512-hit
 //     bucket sort left 2-3 materials in every wave; a window of 4096 leaves most waves with one (deferred_shading_kernel_t buckets
 //     a 1024-slot stream per material for the same reason, deferred_shading_kernel.hpp:9-33, 63).
@@ -868,27 +868,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_SHADE_ITEMS_G 8
 #endif
 #define PHX_SHADE_BUCKETS 64  /* sort key = material mod 64; then the misses; slots past the end of the queue go last */
-template <int BLOCK>
-__device__ __forceinline__ uint32_t block_append1(bool want, uint32_t* counter, uint32_t* lds /* [waves + 1] */) {
-  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = BLOCK >> 6;
-  const unsigned long long mask = __ballot(want);
-  if (lane == 0) lds[wave] = (uint32_t)__popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-#pragma nounroll
-    for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = lds[w]; lds[w] = total; total += c; }
-    lds[nwaves] = total ? atomicAdd(counter, total) : 0u;
-  }
-  __syncthreads();
-  return lds[nwaves] + lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
 template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
   static_assert(WINDOW <= 65536 && BLOCK >= NB + 2 && NB == 64, "perm holds 16-bit positions; one wave scans the NB material buckets");
-  __shared__ uint32_t lds_s[(BLOCK >> 6) + 1], lds_r[(BLOCK >> 6) + 1];
+  __shared__ uint32_t lds_sr[2 * ((BLOCK >> 6) + 1)];
   __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
   __shared__ uint16_t perm[WINDOW];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
@@ -931,7 +915,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       // 5-12 VGPRs and bought 1.2 of 42.7 ms: profiles/r03_q_prefetch_ab.log.  Not kept.)
       // Live ranges are kept short on purpose (the kernel is register-bound: 128 VGPRs as one block of code): radiance and the
       // normals channel are written as soon as the hit is known; the light's record is re-read after the closure evaluation instead
-      // of being held across it; the NEE ray is in its queue before roulette and BSDF sampling start.
+      // of being held across it.
       bool alive = false, want_shadow = false, hit_surface = false;
       uint32_t path = 0, depth = 0, key = 0;
       v3 p, n, wo, beta;
@@ -990,8 +974,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       // the hit's tangent frame (orthogonal_base_t): once per hit, for the NEE evaluation and the BSDF sample
       const Frame fr(hit_surface ? n : v3(0.0f, 1.0f, 0.0f));
       // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
+      v3 sh_o, sh_d, contrib; float sh_t = 0.0f;  // the NEE ray waits in registers for the survivor: both queues are appended in one go below
       {
-        v3 sh_o, sh_d, contrib; float sh_t = 0.0f;
         if (hit_surface) {
           const uint32_t b0 = depth * DIMS_PER_STEP;
           const float pick = draw_f32(key, b0 + DIM_LIGHT_PICK), lu = draw_f32(key, b0 + DIM_LIGHT_U), lv = draw_f32(key, b0 + DIM_LIGHT_V);
@@ -1033,12 +1017,6 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
             want_shadow = true;
           }
         }
-        const uint32_t ns = block_append1<BLOCK>(want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_s);
-        if (want_shadow) {
-          pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
-          pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
-          pb.sc[ns] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
-        }
       }
       // ---- integrate: ++depth, russian roulette, bsdf sampling (spt.hpp:188-190, 257-328)
       {
@@ -1069,7 +1047,16 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           }
         }
         if (alive) pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));  // only the next shade of a surviving path reads it
-        const uint32_t no = block_append1<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], lds_r);
+        // both queues in one go: two barriers and two concurrent atomics per round (appending the NEE ray before roulette and sampling
+        // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
+        // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
+        uint32_t no, ns;
+        block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns);
+        if (want_shadow) {
+          pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
+          pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
+          pb.sc[ns] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+        }
         if (alive) {
           const v3 nxt_o = p + n * off;
           pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
