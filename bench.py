@@ -463,33 +463,63 @@ def main():
         film_dev = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
     else:
         film_host = xpu.Film(W, H, 4)
-    # N > 1: two films, used in turn, so that the reduce of frame k (RCCL's stream) runs beside the rendering of frame k + 1 (the
-    # device's stream); pending[b] = the reduce still reading film b
-    films = [film_dev, torch.zeros_like(film_dev)] if use_dist else [film_dev]
-    pending = [None, None]
+    # N > 1: TWO frames in flight per rank.  A rank's share of a frame is 21 short launches, and every launch ends with a drain in which
+    # the chip empties (17 % of the share at N = 8); a second device object on the same GPU — its own stream, queues
+    # and tree — renders the NEXT frame meanwhile, so one frame's drains are filled by the other frame's launches (frames are
+    # independent; every frame of the timed region starts after the opening barrier and is complete before the closing one).  The
+    # film reduce of a finished frame (RCCL's stream) runs beside both.  Four films in turn; pending[b] = the reduce still reading film b.
+    IN_FLIGHT = 2 if use_dist else 1
+    devs, tile_sets = [dev], [tiles]
+    if use_dist:
+        dev2 = xpu.HipDevice.make(opts); dev2.preprocess(scene)
+        devs.append(dev2); tile_sets.append(xpu.Tiles.make(W, H, 32, rank, world))
+    films = [film_dev] + [torch.zeros_like(film_dev) for _ in range(3)] if use_dist else [film_dev]
+    pending = [None] * len(films)
     frame_no = [0]
 
     def barrier():
         if use_dist:
-            for b in (0, 1):  # every film reduce in flight belongs to the frames before the barrier
+            for b in range(len(films)):  # every film reduce in flight belongs to the frames before the barrier
                 if pending[b] is not None:
                     pending[b].wait(); pending[b] = None
             dist.barrier()
         torch.cuda.synchronize()
 
+    def start_frame(i):
+        """N > 1: frame i goes to device i mod 2 and film i mod 4"""
+        b = i % len(films)
+        if pending[b] is not None:
+            pending[b].wait(); pending[b] = None  # the reduce of four frames ago has read this film (orders torch's stream behind it)
+        films[b].zero_()
+        cleared = torch.cuda.Event(); cleared.record(); cleared.synchronize()  # the device renders on its own stream: wait for the zeros only
+        tile_sets[i % IN_FLIGHT].reset()
+        devs[i % IN_FLIGHT].start(scene, xpu.FrameState(args.seed, tile_sets[i % IN_FLIGHT], None, device_film_ptr=films[b].data_ptr()))
+
+    def finish_frame(i):
+        d = devs[i % IN_FLIGHT]
+        d.join()  # join() synchronises the device's stream: the film is complete
+        pending[i % len(films)] = pdist.reduce_film(films[i % len(films)], dst=0, async_op=True)  # the single film collective (RCCL over xGMI)
+        return d.stats()
+
+    def run_frames(n, acc=None):
+        """n frames, at most IN_FLIGHT of them at a time; returns the stats of the last one"""
+        st, first = None, frame_no[0]
+        for i in range(first, first + n):
+            if i - first >= IN_FLIGHT:
+                st = finish_frame(i - IN_FLIGHT)
+                if acc is not None:
+                    add_stats(acc, st)
+            start_frame(i)
+        for i in range(max(first, first + n - IN_FLIGHT), first + n):
+            st = finish_frame(i)
+            if acc is not None:
+                add_stats(acc, st)
+        frame_no[0] = first + n
+        return st
+
     def step():
         tiles.reset()
-        if use_dist:
-            b = frame_no[0] & 1; frame_no[0] += 1
-            film = films[b]
-            if pending[b] is not None:
-                pending[b].wait()  # the reduce of two frames ago has read this film (orders torch's stream behind it)
-            film.zero_()
-            cleared = torch.cuda.Event(); cleared.record(); cleared.synchronize()  # the device renders on its own stream: wait for the zeros only
-            dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film.data_ptr()))
-            dev.join()  # join() synchronises the device's stream: the film is complete
-            pending[b] = pdist.reduce_film(film, dst=0, async_op=True)  # the single film collective (RCCL over xGMI), overlapped with the next frame
-        elif film_dev is not None:
+        if film_dev is not None:
             # no clearing: at world 1 the device's tiles cover (and overwrite) every pixel of the film
             dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
             dev.join()  # join() synchronises the device's stream
@@ -498,16 +528,25 @@ def main():
             dev.join()
         return dev.stats()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
     acc = new_acc()
-    for _ in range(args.steps):
-        st = step()
-        add_stats(acc, st)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if use_dist:
+        if args.warmup:
+            run_frames(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        st = run_frames(args.steps, acc)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    else:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = step()
+            add_stats(acc, st)
+        barrier()
+        elapsed = time.perf_counter() - t0
     # the same frames once more through the OTHER film sink (N = 1): `value` keeps the film in HBM, `value_host_film` hands every
     # frame to a host frame buffer as xpu_t's add_tile does (the reference's own start...join bracket, src/core.cpp:158-177)
     value_other = None
@@ -530,6 +569,32 @@ def main():
             if i >= 1:
                 so = dev.stats(); rays_o += so["rays_closest"] + so["rays_shadow"]
         value_other = rays_o / (time.perf_counter() - t1) / 1e6
+    # ... and once more with TWO frames in flight (a second device object, its own stream), as every rank of an N > 1 run does: the N = 1
+    # number to hold a multi-GPU `value` against.  `value` itself stays one frame at a time, so that the HIP-event kernel times the
+    # roofline is made of are those of kernels that had the chip to themselves.
+    value_two_in_flight = None
+    if not use_dist and not args.one_sink and film_dev is not None:
+        dev2 = xpu.HipDevice.make(opts); dev2.preprocess(scene)
+        pair = [(dev, tiles, film_dev), (dev2, xpu.Tiles.make(W, H, 32, rank, world), torch.zeros_like(film_dev))]
+        def go(i):
+            d, t, f = pair[i & 1]
+            t.reset(); d.start(scene, xpu.FrameState(args.seed, t, None, device_film_ptr=f.data_ptr()))
+        def done(i):
+            d = pair[i & 1][0]
+            d.join(); sp = d.stats()
+            return sp["rays_closest"] + sp["rays_shadow"]
+        go(0); go(1); done(0); done(1)  # untimed: both devices have rendered a frame
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        rays_p = 0
+        for i in range(args.steps):
+            if i >= 2:
+                rays_p += done(i - 2)
+            go(i)
+        for i in range(max(0, args.steps - 2), args.steps):
+            rays_p += done(i)
+        torch.cuda.synchronize()
+        value_two_in_flight = rays_p / (time.perf_counter() - t2) / 1e6
+        dev2.close()
     rays_local = acc["closest"] + acc["shadow"]
     if use_dist:
         elapsed = pdist.max_over_ranks(elapsed, "cpu" if rehearsal else "cuda")
@@ -539,7 +604,7 @@ def main():
 
     if rank == 0:
         if use_dist:
-            film_dev = films[(frame_no[0] - 1) & 1]  # the film of the last frame, reduced onto this rank
+            film_dev = films[(frame_no[0] - 1) % len(films)]  # the film of the last frame, reduced onto this rank
         film = film_dev.cpu().numpy() if film_dev is not None else film_host.data
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_total / elapsed / 1e6
@@ -549,16 +614,20 @@ def main():
             "dtype": "f32", "data": "synthetic", **({"rehearsal": "all ranks on GPU 0, gloo reduce: not a scaling result"} if rehearsal else {}),
             "value_film": "host (PCIe inside the timed region, --host-film)" if film_dev is None else "hbm (device film: nothing crosses PCIe inside a step)",
             "value_host_film": value if film_dev is None else value_other, "value_hbm_film": value_other if film_dev is None else value,
+            "value_two_frames_in_flight": value_two_in_flight,
             "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "
                                    "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
-                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0, overlapped with the next frame's rendering (two films)" if use_dist else "none",
+                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0, asynchronous, beside the rendering of the next frames" if use_dist else "none",
+                       "frames_in_flight": IN_FLIGHT, **({"frames_in_flight_note": "N > 1: two device objects per rank render alternate frames on their own streams (one frame's "
+                                                          "drain phases are filled by the other's launches); kernel_ms_per_step are HIP-event times of overlapped kernels"} if use_dist else {}),
                        "rays_per_step": rays_total / args.steps, "camera_samples_per_step": W * H * args.spp,
                        "preprocess_s": preprocess_s, "bvh_builder": args.bvh_builder, "bvh_build_ms": st["bvh_build_ms"],
                        "bvh_bytes": st["bvh_bytes"], "paths_in_flight": st["paths_in_flight"],
                        "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
                        "film_mean": float(film[..., :3].mean()), "film_finite": bool(np.isfinite(film).all())},
         }
-        dev.close()
+        for d_ in devs:
+            d_.close()
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             work = count_work(args.triangles, W, H, args.spp, args.bvh_builder)
             base, ref_visits = cpu_baseline(scene, args)
@@ -587,7 +656,8 @@ def main():
         out["config"]["kernel_ms_per_step"] = {**kernel_ms(acc, args.steps), "frame": acc["frame_ms"] / args.steps}
         print(json.dumps(out))
     else:
-        dev.close()
+        for d_ in devs:
+            d_.close()
     if use_dist:
         dist.destroy_process_group()
 
