@@ -75,13 +75,13 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu():
     env = dict(os.environ, PHX_BENCH_REHEARSAL="1")
     port = 29700 + (os.getpid() % 200)
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + [x if x not in ("1", "0") else {"1": "3", "0": "1"}[x] for x in common],  # 3 steps after 1 warm-up: two frames in flight
                          capture_output=True, text=True, timeout=300, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 alone prints
     d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["film_collective"].startswith("reduce") and "rehearsal" in d2
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["film_collective"].startswith("reduce") and "rehearsal" in d2 and d2["config"]["frames_in_flight"] == 2
     assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and d2["config"]["camera_samples_per_step"] == 160 * 96 * 9
     assert d2["config"]["film_mean"] == d1["config"]["film_mean"] and d2["config"]["film_finite"]
     assert d2["roofline"]["frac"] is None and d2["cpu_baseline"] is None  # reported at N = 1 only
