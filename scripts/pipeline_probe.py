@@ -12,7 +12,7 @@ def make():
     d = xpu.HipDevice.make(xpu.Options(samples_per_pixel=256, paths_per_sample=1, path_depth=9))
     d.preprocess(sc)
     return d, xpu.Tiles.make(W, H, 32, 0, world), torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-for ndev in (1, 2):
+for ndev in tuple(int(x) for x in os.environ.get("PROBE_DEVICES", "1,2").split(",")):
     devs = [make() for _ in range(ndev)]
     def start(i):
         d, t, f = devs[i % ndev]
