@@ -116,6 +116,8 @@ def test_newest_committed_bench_record_keeps_the_contract():
         assert all(0 < rf["diagnostics"][k]["frac"] <= 1 for k in ("valu_issue", "vector_l1", "l2", "hbm"))
         assert d["value_hbm_film"] == d["value"] and 0 < d["value_host_film"] < 1.05 * d["value"]
         assert len(d["secondary"]) == 4 and [s["roofline"]["kernel"] for s in d["secondary"]] == ["k_trace", "k_trace", "k_shade_g", "k_shade_g"]
+        if "value_two_frames_in_flight" in d:  # r03_zzg on: the N = 1 rate with two frames in flight, what every rank of an N > 1 run does
+            assert d["config"]["frames_in_flight"] == 1 and 0.9 * d["value"] < d["value_two_frames_in_flight"] < 1.2 * d["value"]
         if "primary" in d:  # r03_zq on: the camera rays have their own kernel, k_trace's roofline is about the other rays
             pr = d["primary"]
             assert pr["kernel"] == "k_trace_primary" and pr["rays_per_step"] == d["config"]["camera_samples_per_step"] and pr["ms_per_step"] > 0
