@@ -1,34 +1,38 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the gfx950 path-tracing device on BASELINE.json's configuration.
 
-A step = one whole frame (xpu_t::start ... join, the reference's own "Rendering time" bracket,
-src/core.cpp:158-177) of the synthetic workload:
-  N=1 : Soup(100k) 1280x720 256 spp, depth 9, pps 1   (BASELINE.json configs[1])
-  N>1 : the same frame, its 32x32 tiles interleaved over the ranks (tile (tx, ty) -> rank (tx + 3 ty) % N), every rank
-        accumulating into its own zero-initialised device film, one RCCL reduce(sum) of the film to
-        rank 0 inside the timed region ("strong" scaling: total work is fixed).
-value = rays traced by ALL ranks (closest-hit + non-masked shadow rays) / max-over-ranks time.
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one whole frame (xpu_t::start ... join, the reference's own "Rendering time" bracket, src/core.cpp:158-177) of the
+synthetic workload Soup(100k) 1280x720 256 spp, depth 9, pps 1 (BASELINE.json configs[1]).  ONE protocol at every N:
+  value   ONE frame in flight.  Its 32x32 tiles are interleaved over the ranks (tile (tx, ty) -> rank (tx + 3 ty) % N), every rank
+          renders into its own device film (HBM) and — N > 1 — the films are summed onto rank 0 with ONE reduce(sum) (RCCL over xGMI)
+          INSIDE the bracket, before the next frame starts ("strong" scaling: total work is fixed).
+          value = rays traced by ALL ranks (closest-hit + non-masked shadow rays) / max-over-ranks time of K frames.
+  value_two_frames_in_flight
+          the same K frames with a second device object per rank (own stream, queues and tree) rendering alternate frames and the
+          film reduce asynchronous beside them: a throughput, not a frame latency; reported at every N, never called `value`.
+  value_host_film (N = 1)
+          the frame handed to a host frame buffer through the xpu_t boundary's add_tile sink (14.7 MB over PCIe per frame).
 Scene upload and BVH build (xpu_t::preprocess) happen before the timed region: inputs are HBM-resident.
 
-Extra objects on the JSON line (N = 1 only):
-  value_host_film  the same frame timed through the host film sink (the xpu_t boundary's add_tile: 14.7 MB over PCIe per frame),
-               the rate the reference's own start...join bracket would see; `value` keeps the film in HBM.
+--gpus N without a torch.distributed environment starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+process (before this process touches the GPU), relays rank 0's line and exits with the child's code; it fails when fewer than N
+devices are visible.  Under the driver's own torchrun launch WORLD_SIZE must equal --gpus.
+
+Output: the LAST stdout line is ONE compact JSON object (< 4 KB: metric, value, roofline, cpu_baseline, four secondary workloads reduced
+to value / ms / roofline fraction).  The FULL record — every operand of the roofline, counter diagnostics, CPU scaling table, complete
+secondary records — goes to --full-json (default gpurun_out/bench_full.json).  At N = 1 the full record carries:
   roofline     of the dominant kernel, k_trace (closest-hit rays of a step + shadow rays of the previous step in one persistent
                launch; time = HIP events on the device's own stream around every launch of the timed steps).
                `frac` is WORK-based (bound "valu"): the node visits and triangle tests the frame needs (counted by the instrumented
                build, libphx_hip_count.so, on the same frame) priced at the rate the chip runs k_trace's own arithmetic with nothing
                else in the way (scripts/micro/valu_mix.hip, profiles/r*_valu_mix.json) = minimum ALU time / k_trace time measured
                in THIS run.  `diagnostics` are counter rates, each taken from ONE committed capture (profiles/r*_<tag>_pmc.json)
-               and divided by the kernel time of THAT capture's --kernel-trace --stats pass (kernel_ms_stats_pass), never by this
-               run's time:
-                 valu_issue    VALU wave-instructions issued vs 256 CUs x 4 SIMDs x 1 per 2 clocks (rewards wasted instructions:
-                               a diagnostic, not the fraction)
-                 vector_l1     vector-L1 lane addresses vs the measured 1.7 per clock and CU (scripts/micro/l1_gather.hip)
-                 l2            L1->L2 read requests x 64 B vs 34.5 TB/s
-                 hbm           FETCH_SIZE x 2 + WRITE_SIZE (separate PMC passes, MI355X_MICROARCH.md) vs 8 TB/s; `traffic` = those
-                               bytes per launch
-               `algorithmic_ref_layout` keeps SURVEY 8(d)'s figure (bytes per ray in the REFERENCE's 288-B node / 384-B packet
-               layout, V_n and V_l from the CPU restatement's counters): a work-normalised rate, not a bound.
+               and divided by the kernel time of THAT capture's --kernel-trace --stats pass, never by this run's time
+               (valu_issue, vector_l1, l2, hbm = FETCH_SIZE x 2 + WRITE_SIZE vs 8 TB/s; `traffic` = those bytes per launch).
+               `stream_GBps` = the compulsory queue bytes of this kernel (48 B per closest-hit ray, 80 B per shadow ray) over its
+               live HIP-event time: the HBM-roofline reading of the same launches (the tree is L2-resident, so it is far from 8 TB/s).
   cpu_baseline the CPU restatement (oracle/, kind "port") on this box's host cores: a warm thread pool renders tiles of the same
                frame (counter RNG) for >= 10 s; thread start-up and per-thread stream construction are outside the clock.
   secondary    the same measurement on Soup(1 M) (the north star's target scene), on the whole BASELINE config-4 frame
@@ -57,7 +61,7 @@ L1_ADDR_PER_CLK_CU = 1.7  # measured ceiling of the vector L1: lane addresses pe
 COUNT_LIB = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
@@ -76,9 +80,9 @@ def parse():
     p.add_argument("--bvh-builder", choices=["auto", "host", "device"], default="auto",
                    help="auto (host binned SAH up to 2 M triangles, device LBVH above), host, device")
     p.add_argument("--force-dist", action="store_true", help="use torch.distributed + the film reduce even at N=1")
-    p.add_argument("--one-sink", action="store_true", help="do not time the frames a second time through the other film sink (profiling captures: one frame per run)")
-    p.add_argument("--host-film", action="store_true", help="N=1: hand the frame to the host film sink (PCIe inside the timed region) instead of a device film")
-    return p.parse_args()
+    p.add_argument("--one-sink", action="store_true", help="time `value` only: no host-film pass, no two-frames-in-flight pass (profiling captures: one frame per run)")
+    p.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"), help="where the full record goes (the stdout line is the compact one)")
+    return p.parse_args(argv)
 
 
 # ---- host CPUs ----------------------------------------------------------------------------------------------
@@ -246,6 +250,12 @@ def roofline(acc, steps, work, tag, ref_visits):
     roof = {"kernel": "k_trace", "launches_per_step": nl / steps, "avg_launch_ms": t_launch * 1e3,
             "rays_per_launch": (rays_c + rays_s) * steps / nl, "kernel_rays_per_s": (rays_c + rays_s) / t_frame,
             "bound": "valu", "achieved": None, "peak": None, "unit": "G node-visit equivalents/s", "frac": None, "traffic": None}
+    # the HBM reading of the same launches: compulsory queue bytes (closest-hit ray 32 in + 16 hit record out; shadow ray 48 in + 32 of
+    # radiance read-modify-write) over the live HIP-event time.  The 8 MB tree is L2-resident, so this is far from the 8 TB/s peak.
+    stream_bytes = rays_c * 48.0 + rays_s * 80.0
+    roof["stream_GBps"] = stream_bytes / t_frame / 1e9
+    roof["stream_bytes_per_launch"] = stream_bytes * steps / nl
+    roof["stream_frac_of_hbm_peak"] = stream_bytes / t_frame / 1e9 / HBM_PEAK_GBS
     peak, peak_src = committed_valu_peak()
     if work and "error" not in work and peak:
         nv = sum(work[k]["rays"] * (work[k]["node_visits_lds_per_ray"] + work[k]["node_visits_mem_per_ray"]) for k in ("closest", "shadow"))
@@ -400,7 +410,7 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
                               cpu_seconds=cpu_seconds)
     value, ms, acc, st, pre, scene, film, value_host = run_workload(xpu, scenes, kind, triangles, width, height, spp, args.depth, args.seed, "auto", steps=2, warmup=1)
     rec = {"workload": name, "value": value, "value_host_film": value_host, "unit": "Mrays/s", "ms_per_step": ms, "steps": 2, "rays_per_step": (acc["closest"] + acc["shadow"]) / 2,
-           "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"],
+           "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"], "hbm_bytes": st["device_bytes"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
            "kernel_ms_per_step": kernel_ms(acc, 2), "film_finite": bool(np.isfinite(film).all())}
     tag = workload_tag(kind, triangles, width, height, args.depth)
@@ -421,26 +431,166 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
     return rec
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+# ---- --gpus N: who runs what ---------------------------------------------------------------------------------
+def launch_decision(gpus, env, visible_devices, rehearsal=False):
+    """What `bench.py --gpus N` does, decided before anything touches the GPU (src/core.cpp:103-115 makes one device per GPU; here it is
+    one PROCESS per GPU).  -> ("run", world) render in this process as one rank of `world`;
+                              ("spawn", N)  start torch.distributed.run with N ranks as a child process and relay its line;
+                              ("error", message)."""
+    if gpus < 1:
+        return ("error", f"--gpus {gpus}: need at least one GPU")
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:  # launched by torch.distributed.run (the driver's N > 1 launch, or our own child)
+        if int(ws) != gpus:
+            return ("error", f"--gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus}")
+        if not rehearsal and visible_devices is not None and visible_devices < gpus:
+            return ("error", f"--gpus {gpus} but only {visible_devices} GPU(s) visible: ranks would share a device")
+        return ("run", gpus)
+    if gpus == 1:
+        return ("run", 1)
+    if not rehearsal and visible_devices is not None and visible_devices < gpus:
+        return ("error", f"--gpus {gpus} but only {visible_devices} GPU(s) visible: ranks would share a device")
+    return ("spawn", gpus)
+
+
+def visible_gpus():
+    """number of HIP devices, without initialising the GPU in this process (torch.cuda.device_count() does not, on this image)"""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return None
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """python -m torch.distributed.run --nproc-per-node n bench.py <argv> as a CHILD process (never exec: this process may not replace
+    itself once a GPU runtime is loaded, and it has not touched the GPU).  Everything the ranks print is relayed; rank 0's JSON line
+    is held back and printed LAST.  Returns the child's exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    result = None
+    for line in child.stdout:
+        if line.startswith('{"metric"'):
+            result = line.rstrip("\n")
+        else:
+            sys.stdout.write(line); sys.stdout.flush()
+    rc = child.wait()
+    if result is not None:
+        print(result, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ---- the compact line -----------------------------------------------------------------------------------------
+LINE_BUDGET = 4096  # bytes of the final stdout line (round 3's 21.9 KB line could not be parsed by the driver)
+
+
+def _r(x, n=6):
+    """numbers to n significant digits: the line is for a reader, the full record keeps every digit"""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    return x
+
+
+def compact_roofline(rf):
+    if not rf:
+        return None
+    out = {k: _r(rf.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step")}
+    hbm = (rf.get("diagnostics") or {}).get("hbm")
+    out["hbm_GBps"] = _r(hbm["achieved"]) if hbm else None     # counter bytes of the committed capture / the kernel's time IN that capture
+    out["hbm_frac"] = _r(hbm["frac"]) if hbm else None
+    if "stream_GBps" in rf:
+        out["stream_GBps"] = _r(rf["stream_GBps"])             # compulsory queue bytes / live HIP-event time of this run
+    if rf.get("diagnostics"):
+        out["counters_from"] = rf["diagnostics"]["source"]
+    return out
+
+
+def compact_line(full, full_path):
+    """the <= 4 KB line the driver parses, made from the full record"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "value_definition", "value_host_film", "value_two_frames_in_flight", "rehearsal")
+    out = {k: _r(full[k]) for k in keep if k in full}
+    c = full["config"]
+    out["config"] = {k: _r(c[k]) for k in ("workload", "tiles", "film_collective", "frames_in_flight", "rays_per_step", "hbm_bytes_per_rank",
+                                           "hbm_bytes_per_rank_two_frames_in_flight", "film_mean", "film_finite", "gpu_over_cpu") if k in c}
+    if "kernel_ms_per_step" in c:
+        out["config"]["kernel_ms_per_step"] = {k: _r(v, 4) for k, v in c["kernel_ms_per_step"].items()}
+    out["roofline"] = compact_roofline(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None
+    if full.get("secondary"):
+        out["secondary"] = [{"workload": s["workload"][:72], "value": _r(s["value"]), "ms_per_step": _r(s["ms_per_step"], 5),
+                             "roofline": {"kernel": s["roofline"]["kernel"], "bound": s["roofline"]["bound"], "frac": _r(s["roofline"]["frac"], 4)}}
+                            for s in full["secondary"]]
+    out["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
+    line = json.dumps(out)
+    if len(line) >= LINE_BUDGET:  # never again an unparseable line: drop the optional parts first
+        for k in ("secondary", "full_record"):
+            out.pop(k, None)
+            line = json.dumps(out)
+            if len(line) < LINE_BUDGET:
+                break
+    assert len(line) < LINE_BUDGET, len(line)
+    return line
+
+
+def write_full(full, path):
+    if not path:
+        return None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(json.dumps(full) + "\n")
+        return path
+    except OSError as e:
+        print(f"bench.py: full record not written ({e})", file=sys.stderr)
+        return None
+
+
+VALUE_DEFINITION = ("rays of all ranks / max-over-ranks wall time of K frames, ONE frame in flight; inputs (scene, BVH) and the film stay in HBM, "
+                    "N > 1: one reduce(sum) of the film to rank 0 inside the bracket; value_host_film = the same frames through the host "
+                    "film sink (PCIe, the reference's own start...join bracket); value_two_frames_in_flight = pipelined throughput")
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
     # Rehearsal of the N > 1 path on a ONE-GPU box (PHX_BENCH_REHEARSAL=1, never set by the driver): every rank uses GPU 0 and the
-    # film reduce runs on gloo, because two RCCL ranks cannot share a device.  Everything else — tile shard, device films, the reduce,
-    # max-over-ranks timing, the rays summed over ranks — is the code the real N-GPU run takes.  The number it prints is not a result.
+    # film reduce runs on gloo, because two RCCL ranks cannot share a device.  Everything else — the launch, tile shard, device films,
+    # the reduce, max-over-ranks timing, the rays summed over ranks — is the code the real N-GPU run takes.  Its number is not a result.
     rehearsal = os.environ.get("PHX_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
+    what, arg = launch_decision(args.gpus, os.environ, visible_gpus(), rehearsal)
+    if what == "error":
+        print("bench.py: " + arg, file=sys.stderr)
+        return 2
+    if what == "spawn":
+        return spawn_ranks(arg, argv)
+    world = arg
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
-    dist = None
+    dist = pdist = None
     # torch first: libphx_hip.so then binds to the HIP runtime torch already loaded (one runtime per process).  torch is plumbing
     # here: the film's device memory and, at N > 1, the process group.
     import torch
     torch.cuda.set_device(local_rank)
+    cuda = torch.device("cuda", local_rank)
     if use_dist:
         from phosphorus_mk2_amd import dist as pdist
-        dist = pdist.init_process_group("gloo" if rehearsal else "nccl", rank, world, None if rehearsal else torch.device("cuda", local_rank))
+        dist = pdist.init_process_group("gloo" if rehearsal else "nccl", rank, world, None if rehearsal else cuda)
     from phosphorus_mk2_amd import scenes, xpu
     xpu.load_library()  # raises if the HIP extension is missing: no fallback
 
@@ -448,186 +598,154 @@ def main():
     opts = xpu.Options(samples_per_pixel=args.spp, paths_per_sample=1, path_depth=args.depth,
                        device_ordinal=local_rank, samples_in_flight=args.samples_in_flight,
                        bvh_builder=args.bvh_builder)
-    dev = xpu.HipDevice.make(opts)
+    W, H = args.width, args.height
     t0 = time.time()
+    dev = xpu.HipDevice.make(opts)
     dev.preprocess(scene)  # flatten + BVH build + upload: outside the timed region
     preprocess_s = time.time() - t0
-    W, H = args.width, args.height
     tiles = xpu.Tiles.make(W, H, 32, rank, world)
-    # The film stays in HBM inside the timed region (`value` is HBM-resident in, HBM-resident out); --host-film times the frame
-    # through the host film sink instead — 14.7 MB over PCIe per frame, what a host that hands over a frame buffer sees: the
-    # PCIe-inclusive rate DESIGN.md section 5 quotes beside `value`.
-    film_host = None
-    film_dev = None
-    if use_dist or not args.host_film:
-        film_dev = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
-    else:
-        film_host = xpu.Film(W, H, 4)
-    # N > 1: TWO frames in flight per rank.  A rank's share of a frame is 21 short launches, and every launch ends with a drain in which
-    # the chip empties (17 % of the share at N = 8); a second device object on the same GPU — its own stream, queues
-    # and tree — renders the NEXT frame meanwhile, so one frame's drains are filled by the other frame's launches (frames are
-    # independent; every frame of the timed region starts after the opening barrier and is complete before the closing one).  The
-    # film reduce of a finished frame (RCCL's stream) runs beside both.  Four films in turn; pending[b] = the reduce still reading film b.
-    IN_FLIGHT = 2 if use_dist else 1
-    devs, tile_sets = [dev], [tiles]
-    if use_dist:
-        dev2 = xpu.HipDevice.make(opts); dev2.preprocess(scene)
-        devs.append(dev2); tile_sets.append(xpu.Tiles.make(W, H, 32, rank, world))
-    films = [film_dev] + [torch.zeros_like(film_dev) for _ in range(3)] if use_dist else [film_dev]
-    pending = [None] * len(films)
-    frame_no = [0]
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=cuda)  # the film stays in HBM inside the timed region
+    red_dev = "cpu" if rehearsal else "cuda"
 
     def barrier():
         if use_dist:
-            for b in range(len(films)):  # every film reduce in flight belongs to the frames before the barrier
-                if pending[b] is not None:
-                    pending[b].wait(); pending[b] = None
             dist.barrier()
         torch.cuda.synchronize()
 
-    def start_frame(i):
-        """N > 1: frame i goes to device i mod 2 and film i mod 4"""
-        b = i % len(films)
-        if pending[b] is not None:
-            pending[b].wait(); pending[b] = None  # the reduce of four frames ago has read this film (orders torch's stream behind it)
-        films[b].zero_()
-        cleared = torch.cuda.Event(); cleared.record(); cleared.synchronize()  # the device renders on its own stream: wait for the zeros only
-        tile_sets[i % IN_FLIGHT].reset()
-        devs[i % IN_FLIGHT].start(scene, xpu.FrameState(args.seed, tile_sets[i % IN_FLIGHT], None, device_film_ptr=films[b].data_ptr()))
-
-    def finish_frame(i):
-        d = devs[i % IN_FLIGHT]
-        d.join()  # join() synchronises the device's stream: the film is complete
-        pending[i % len(films)] = pdist.reduce_film(films[i % len(films)], dst=0, async_op=True)  # the single film collective (RCCL over xGMI)
-        return d.stats()
-
-    def run_frames(n, acc=None):
-        """n frames, at most IN_FLIGHT of them at a time; returns the stats of the last one"""
-        st, first = None, frame_no[0]
-        for i in range(first, first + n):
-            if i - first >= IN_FLIGHT:
-                st = finish_frame(i - IN_FLIGHT)
-                if acc is not None:
-                    add_stats(acc, st)
-            start_frame(i)
-        for i in range(max(first, first + n - IN_FLIGHT), first + n):
-            st = finish_frame(i)
-            if acc is not None:
-                add_stats(acc, st)
-        frame_no[0] = first + n
-        return st
-
-    def step():
+    # ---- `value`: ONE frame in flight, the reduce inside the bracket — the same protocol at every N -------------------------------
+    def one_frame():
+        if use_dist:
+            # the reduce leaves the SUM in rank 0's film: every rank starts a frame from zeros.  zero_() runs on torch's stream behind the
+            # previous frame's reduce; the device renders on its own stream, so wait for the zeros on the host.
+            film.zero_()
+            ev = torch.cuda.Event(); ev.record(); ev.synchronize()
         tiles.reset()
-        if film_dev is not None:
-            # no clearing: at world 1 the device's tiles cover (and overwrite) every pixel of the film
-            dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_dev.data_ptr()))
-            dev.join()  # join() synchronises the device's stream
-        else:
-            dev.start(scene, xpu.FrameState(args.seed, tiles, film_host, native_sink=True))
-            dev.join()
+        dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film.data_ptr()))
+        dev.join()  # join() synchronises the device's stream: this rank's tiles are in its film
+        if use_dist:
+            pdist.reduce_film(film, dst=0)  # the frame's single collective (RCCL over xGMI); complete before the next zero_() / the barrier
+            if rehearsal:
+                pass  # gloo reduces synchronously
         return dev.stats()
 
     acc = new_acc()
-    if use_dist:
-        if args.warmup:
-            run_frames(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        st = run_frames(args.steps, acc)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    else:
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            st = step()
-            add_stats(acc, st)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    # the same frames once more through the OTHER film sink (N = 1): `value` keeps the film in HBM, `value_host_film` hands every
-    # frame to a host frame buffer as xpu_t's add_tile does (the reference's own start...join bracket, src/core.cpp:158-177)
-    value_other = None
+    st = None
+    for _ in range(args.warmup):
+        one_frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = one_frame()
+        add_stats(acc, st)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hbm_one = st["device_bytes"] + film.numel() * 4
+    film_np = None
+    if rank == 0:
+        film_np = film.cpu().numpy()  # the last frame of the timed region, reduced onto this rank
+
+    # ---- `value_two_frames_in_flight`: a second device object renders alternate frames, the reduce is asynchronous ----------------
+    value_two = None
+    hbm_two = None
+    if not args.one_sink:
+        dev2 = xpu.HipDevice.make(opts); dev2.preprocess(scene)
+        devs, tile_sets = [dev, dev2], [tiles, xpu.Tiles.make(W, H, 32, rank, world)]
+        films = [film] + [torch.zeros_like(film) for _ in range(3 if use_dist else 1)]  # N > 1: four in turn, a reduce may still read one
+        pending = [None] * len(films)
+
+        def go(i):
+            b = i % len(films)
+            if use_dist:
+                if pending[b] is not None:
+                    pending[b].wait(); pending[b] = None  # the reduce of four frames ago has read this film
+                films[b].zero_()
+                ev = torch.cuda.Event(); ev.record(); ev.synchronize()
+            tile_sets[i & 1].reset()
+            devs[i & 1].start(scene, xpu.FrameState(args.seed, tile_sets[i & 1], None, device_film_ptr=films[b].data_ptr()))
+
+        def done(i):
+            d = devs[i & 1]
+            d.join()
+            if use_dist:
+                pending[i % len(films)] = pdist.reduce_film(films[i % len(films)], dst=0, async_op=True)
+            sp = d.stats()
+            return sp["rays_closest"] + sp["rays_shadow"]
+
+        def drain():
+            for b in range(len(films)):
+                if pending[b] is not None:
+                    pending[b].wait(); pending[b] = None
+
+        def frames(first, n):
+            rays = 0
+            for i in range(first, first + n):
+                if i - first >= 2:
+                    rays += done(i - 2)
+                go(i)
+            for i in range(max(first, first + n - 2), first + n):
+                rays += done(i)
+            return rays
+
+        frames(0, max(2, args.warmup))  # untimed: both devices have rendered a frame
+        drain(); barrier()
+        t2 = time.perf_counter()
+        rays_p = frames(max(2, args.warmup), args.steps)
+        drain(); barrier()
+        el2 = time.perf_counter() - t2
+        hbm_two = dev.stats()["device_bytes"] + dev2.stats()["device_bytes"] + sum(f.numel() * 4 for f in films)
+        if use_dist:
+            el2 = pdist.max_over_ranks(el2, red_dev); rays_p = pdist.sum_over_ranks(rays_p, red_dev)
+        value_two = rays_p / el2 / 1e6
+        dev2.close()
+        del films
+
+    # ---- `value_host_film` (N = 1): the same frames through the host film sink ----------------------------------------------------
+    value_host = None
     if not use_dist and not args.one_sink:
-        other_dev = film_dev is None
-        if other_dev:
-            film_other = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
-        else:
-            film_other = xpu.Film(W, H, 4)
+        host = xpu.Film(W, H, 4)
         rays_o = 0
-        for i in range(1 + args.steps):
+        for i in range(1 + args.steps):  # one untimed frame sizes the pinned staging buffer
             if i == 1:
                 torch.cuda.synchronize(); t1 = time.perf_counter()
             tiles.reset()
-            if other_dev:
-                dev.start(scene, xpu.FrameState(args.seed, tiles, None, device_film_ptr=film_other.data_ptr()))
-            else:
-                dev.start(scene, xpu.FrameState(args.seed, tiles, film_other, native_sink=True))
-            dev.join()
+            dev.start(scene, xpu.FrameState(args.seed, tiles, host, native_sink=True)); dev.join()
             if i >= 1:
                 so = dev.stats(); rays_o += so["rays_closest"] + so["rays_shadow"]
-        value_other = rays_o / (time.perf_counter() - t1) / 1e6
-    # ... and once more with TWO frames in flight (a second device object, its own stream), as every rank of an N > 1 run does: the N = 1
-    # number to hold a multi-GPU `value` against.  `value` itself stays one frame at a time, so that the HIP-event kernel times the
-    # roofline is made of are those of kernels that had the chip to themselves.
-    value_two_in_flight = None
-    if not use_dist and not args.one_sink and film_dev is not None:
-        dev2 = xpu.HipDevice.make(opts); dev2.preprocess(scene)
-        pair = [(dev, tiles, film_dev), (dev2, xpu.Tiles.make(W, H, 32, rank, world), torch.zeros_like(film_dev))]
-        def go(i):
-            d, t, f = pair[i & 1]
-            t.reset(); d.start(scene, xpu.FrameState(args.seed, t, None, device_film_ptr=f.data_ptr()))
-        def done(i):
-            d = pair[i & 1][0]
-            d.join(); sp = d.stats()
-            return sp["rays_closest"] + sp["rays_shadow"]
-        go(0); go(1); done(0); done(1)  # untimed: both devices have rendered a frame
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        rays_p = 0
-        for i in range(args.steps):
-            if i >= 2:
-                rays_p += done(i - 2)
-            go(i)
-        for i in range(max(0, args.steps - 2), args.steps):
-            rays_p += done(i)
-        torch.cuda.synchronize()
-        value_two_in_flight = rays_p / (time.perf_counter() - t2) / 1e6
-        dev2.close()
+        value_host = rays_o / (time.perf_counter() - t1) / 1e6
+
     rays_local = acc["closest"] + acc["shadow"]
     if use_dist:
-        elapsed = pdist.max_over_ranks(elapsed, "cpu" if rehearsal else "cuda")
-        rays_total = pdist.sum_over_ranks(rays_local, "cpu" if rehearsal else "cuda")
+        elapsed = pdist.max_over_ranks(elapsed, red_dev)
+        rays_total = pdist.sum_over_ranks(rays_local, red_dev)
+        hbm_one = pdist.max_over_ranks(hbm_one, red_dev)
+        if hbm_two is not None:
+            hbm_two = pdist.max_over_ranks(hbm_two, red_dev)
     else:
         rays_total = float(rays_local)
+    dev.close()
 
+    rc = 0
     if rank == 0:
-        if use_dist:
-            film_dev = films[(frame_no[0] - 1) % len(films)]  # the film of the last frame, reduced onto this rank
-        film = film_dev.cpu().numpy() if film_dev is not None else film_host.data
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_total / elapsed / 1e6
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", **({"rehearsal": "all ranks on GPU 0, gloo reduce: not a scaling result"} if rehearsal else {}),
-            "value_film": "host (PCIe inside the timed region, --host-film)" if film_dev is None else "hbm (device film: nothing crosses PCIe inside a step)",
-            "value_host_film": value if film_dev is None else value_other, "value_hbm_film": value_other if film_dev is None else value,
-            "value_two_frames_in_flight": value_two_in_flight,
+            "value_definition": VALUE_DEFINITION, "value_host_film": value_host, "value_two_frames_in_flight": value_two,
             "config": {"workload": f"Soup({args.triangles}, seed 1234) {W}x{H} {args.spp} spp depth {args.depth} pps 1, "
                                    "1 emissive quad, Lambert 0.73 (BASELINE.json configs[1])",
-                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus", "film_collective": "reduce(sum) to rank 0, asynchronous, beside the rendering of the next frames" if use_dist else "none",
-                       "frames_in_flight": IN_FLIGHT, **({"frames_in_flight_note": "N > 1: two device objects per rank render alternate frames on their own streams (one frame's "
-                                                          "drain phases are filled by the other's launches); kernel_ms_per_step are HIP-event times of overlapped kernels"} if use_dist else {}),
+                       "tiles": "32x32, tile (tx, ty) -> rank (tx + 3 ty) % n_gpus",
+                       "film_collective": "reduce(sum) to rank 0, inside the bracket" if use_dist else "none",
+                       "frames_in_flight": 1,  # of `value`, at every N
+                       "hbm_bytes_per_rank": int(hbm_one), "hbm_bytes_per_rank_two_frames_in_flight": int(hbm_two) if hbm_two is not None else None,
                        "rays_per_step": rays_total / args.steps, "camera_samples_per_step": W * H * args.spp,
                        "preprocess_s": preprocess_s, "bvh_builder": args.bvh_builder, "bvh_build_ms": st["bvh_build_ms"],
                        "bvh_bytes": st["bvh_bytes"], "paths_in_flight": st["paths_in_flight"],
                        "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
-                       "film_mean": float(film[..., :3].mean()), "film_finite": bool(np.isfinite(film).all())},
+                       "film_mean": float(film_np[..., :3].mean()), "film_finite": bool(np.isfinite(film_np).all())},
         }
-        for d_ in devs:
-            d_.close()
+        assert out["n_gpus"] == args.gpus
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             work = count_work(args.triangles, W, H, args.spp, args.bvh_builder)
             base, ref_visits = cpu_baseline(scene, args)
@@ -641,10 +759,10 @@ def main():
                                             "soup", 1000000, 1280, 720, 256, args, cpu_seconds=args.cpu_seconds))
                 sec.append(secondary_record(xpu, scenes, "Soup(10000000, seed 1234) 3840x2160 256 spp depth 9: the whole BASELINE config-4 frame on ONE GPU",
                                             "soup", 10000000, 3840, 2160, 256, args, cpu_seconds=0))
-                sec.append(secondary_record(xpu, scenes, "stand-in for BASELINE config 3 (no BMW scene ships with the reference): multi_material_soup(500000), 16 closure "
+                sec.append(secondary_record(xpu, scenes, "config-3 stand-in (no BMW scene ships with the reference): multi_material_soup(500000), 16 closure "
                                             "recipes over all 7 lobe models, 1920x1080, 256 of 1024 spp, depth 9, whole frame on one GPU",
                                             "zoo", 500000, 1920, 1080, 256, args, cpu_seconds=0))
-                sec.append(secondary_record(xpu, scenes, "stand-in for BASELINE config 5: the same 16-recipe scene at 3840x2160, 64 of 4096 spp, depth 9, whole frame on one GPU "
+                sec.append(secondary_record(xpu, scenes, "config-5 stand-in: the same 16-recipe scene at 3840x2160, 64 of 4096 spp, depth 9, whole frame on one GPU "
                                             "(the shading-bound regime: k_shade_g)",
                                             "zoo", 500000, 3840, 2160, 64, args, cpu_seconds=0))
                 out["secondary"] = sec
@@ -654,13 +772,13 @@ def main():
                 "bound": None, "kernel": "k_trace", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "note": "roofline and cpu_baseline are reported at N = 1"}
         out["config"]["kernel_ms_per_step"] = {**kernel_ms(acc, args.steps), "frame": acc["frame_ms"] / args.steps}
-        print(json.dumps(out))
-    else:
-        for d_ in devs:
-            d_.close()
+        path = write_full(out, args.full_json)
+        print(compact_line(out, path), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

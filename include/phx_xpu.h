@@ -231,6 +231,7 @@ typedef struct phx_stats {
   uint64_t primary_node_tests; /* instrumented: node tests per packet (one test serves its 64 rays), summed */
   uint64_t primary_tri_tests;  /* instrumented: triangles a packet reached (each is tested by its 64 lanes), summed */
   uint64_t primary_tri_lanes_hit; /* instrumented: lanes whose closest hit a triangle test improved, summed */
+  uint64_t device_bytes;       /* HBM this device object holds right now: tree, scene tables, ray / hit / shadow queues, path state, batch buffer */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

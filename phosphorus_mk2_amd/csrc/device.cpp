@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -66,6 +67,7 @@ struct DevBuf {
   }
   void adopt(T* ptr, size_t count) { release(); p = ptr; n = count; }  // take ownership of a hipMalloc'd array
   void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  size_t bytes() const { return p ? std::max<size_t>(n, 1) * sizeof(T) : 0; }
   ~DevBuf() { release(); }
 };
 
@@ -123,6 +125,14 @@ struct phx_device {
     }
     *out = events[events_used++];
     return PHX_OK;
+  }
+  // HBM held by this device object (phx_stats::device_bytes)
+  uint64_t device_bytes() const {
+    uint64_t b = d_pool.bytes() + d_prim_material.bytes() + d_prim_normals.bytes() + d_spill.bytes() + d_materials.bytes() + d_mat_lite.bytes() +
+                 d_lights.bytes() + d_light_tris.bytes() + hit.bytes() + so.bytes() + sd.bytes() + sc.bytes() + pb.bytes() + pr.bytes() + pn.bytes() +
+                 counters.bytes() + dstats.bytes() + pix_xy.bytes() + jitter.bytes() + acc.bytes();
+    for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes();
+    return b;
   }
   int run_frame();
   int render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit);
@@ -338,16 +348,24 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   const uint32_t builder = d->opt.bvh_builder;
   const uint32_t ntri = (uint32_t)prim_material.size();
   if (builder > PHX_BVH_HOST_SAH) return fail(PHX_ERR_ARG, "unknown bvh_builder");
-  const bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri < 64u);
-  const bool want_device = !want_host;
+  bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri < 64u);
   GpuBvh g{};
-  if (want_device) {
+  if (!want_host) {
     // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
     DevBuf<float> d_abc;
-    if ((rc = d_abc.upload(abc))) return rc;
     char msg[256] = {0};
-    if (build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg)))
-      return fail(PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
+    const bool force_fail = std::getenv("PHX_TEST_FAIL_DEVICE_BUILD") != nullptr;  // test hook (tests/test_gpu_parity.py), read per call
+    rc = d_abc.upload(abc);
+    int brc = rc ? 1 : (force_fail ? (std::snprintf(msg, sizeof(msg), "forced failure (PHX_TEST_FAIL_DEVICE_BUILD)"), 1)
+                                   : build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg)));
+    if (brc) {
+      // An explicit DEVICE_LBVH request fails loudly.  Under AUTO the host's binned-SAH builder handled every scene before the device
+      // builder became the default, so a device build that cannot get its scratch memory (or meets a tree deeper than its tables)
+      // falls back to it: clear the sticky HIP error, build on the host, and say so in phx_stats::bvh_built_on_device.
+      if (builder != PHX_BVH_AUTO) return rc ? rc : fail(PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
+      (void)hipGetLastError();
+      want_host = true;
+    }
   }
   uint32_t bvh_depth = 0; size_t bvh_node_count = 0, bvh_elems = 0;
   SceneGrid bvh_grid{};
@@ -469,6 +487,7 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   out->paths_in_flight = d->paths_in_flight;
   out->bvh_cost_model = d->bvh_cost_model; out->bvh_built_on_device = d->bvh_built_on_device;
   out->shade_general = d->scene.diffuse_only ? 0 : 1;
+  out->device_bytes = d->device_bytes();
   return PHX_OK;
 }
 

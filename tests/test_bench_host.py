@@ -111,7 +111,14 @@ def test_newest_committed_bench_record_keeps_the_contract():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert all(s["film_finite"] and 0 < s["roofline"]["frac"] <= 1 for s in d["secondary"])
-    if os.path.basename(recs[-1]) >= "r03":  # round 3 on: work-based fraction, both film sinks, the config 3 / 5 stand-ins
+    if os.path.basename(recs[-1]) >= "r04":  # round 4 on: one protocol at every N, the stdout line is a compact digest of this record
+        assert d["config"]["frames_in_flight"] == 1 and "one frame in flight" in d["value_definition"].lower()
+        assert 0 < d["value_host_film"] < 1.05 * d["value"] and 0.9 * d["value"] < d["value_two_frames_in_flight"] < 1.25 * d["value"]
+        assert d["config"]["hbm_bytes_per_rank"] > d["config"]["bvh_bytes"] and d["config"]["hbm_bytes_per_rank_two_frames_in_flight"] > d["config"]["hbm_bytes_per_rank"]
+        assert rf["bound"] == "valu" and abs(rf["frac"] - rf["work"]["min_alu_ms_per_frame"] / rf["work"]["k_trace_ms_per_frame"]) < 1e-9
+        assert 0 < rf["stream_GBps"] < 8000 and all(0 < rf["diagnostics"][k]["frac"] <= 1 for k in ("valu_issue", "vector_l1", "l2", "hbm"))
+        assert len(d["secondary"]) == 4 and [s["roofline"]["kernel"] for s in d["secondary"]] == ["k_trace", "k_trace", "k_shade_g", "k_shade_g"]
+    elif os.path.basename(recs[-1]) >= "r03":  # round 3: work-based fraction, both film sinks, the config 3 / 5 stand-ins
         assert rf["bound"] == "valu" and abs(rf["frac"] - rf["work"]["min_alu_ms_per_frame"] / rf["work"]["k_trace_ms_per_frame"]) < 1e-9
         assert all(0 < rf["diagnostics"][k]["frac"] <= 1 for k in ("valu_issue", "vector_l1", "l2", "hbm"))
         assert d["value_hbm_film"] == d["value"] and 0 < d["value_host_film"] < 1.05 * d["value"]
@@ -125,3 +132,53 @@ def test_newest_committed_bench_record_keeps_the_contract():
             assert abs(rf["kernel_rays_per_s"] - (d["config"]["rays_per_step"] - pr["rays_per_step"]) / (rf["work"]["k_trace_ms_per_frame"] * 1e-3)) < 1e-6 * rf["kernel_rays_per_s"]
     else:
         assert all(0 < c["frac"] <= 1 for c in rf["ceilings"].values()) and rf["bound"] in rf["ceilings"] and len(d["secondary"]) == 2
+
+
+def test_the_stdout_line_is_a_compact_digest_that_a_4_KB_reader_can_parse():
+    """round 3's line grew to 21.9 KB and the driver recorded `parsed: null`: the line bench.py prints is now made from the full record
+    by compact_line() and must stay under LINE_BUDGET whatever the full record holds — checked on the newest committed full record"""
+    import glob, json
+    import bench
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_full.json")))
+    full = json.loads(open(recs[-1]).read().strip().splitlines()[-1])
+    full.setdefault("value_definition", bench.VALUE_DEFINITION)
+    line = bench.compact_line(full, os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    assert len(line) < bench.LINE_BUDGET == 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert abs(d["value"] - full["value"]) < 1e-5 * full["value"] and "workload" in d["config"] and "model" not in d["config"]
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["kernel"] == "k_trace" and d["roofline"]["traffic"] > 1e9
+    assert 0 < d["roofline"]["hbm_frac"] < 1 and d["roofline"]["hbm_GBps"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert len(d["secondary"]) == 4 and all(set(s) == {"workload", "value", "ms_per_step", "roofline"} and 0 < s["roofline"]["frac"] <= 1 for s in d["secondary"])
+    # a record ten times as rich still fits: the optional parts go first, the contract keys stay
+    fat = dict(full, secondary=full["secondary"] * 12)
+    line = bench.compact_line(fat, None)
+    assert len(line) < bench.LINE_BUDGET and json.loads(line)["roofline"]["frac"] == d["roofline"]["frac"]
+
+
+def test_gpus_flag_decides_the_launch_before_anything_touches_the_gpu():
+    """--gpus N (src/core.cpp:103-115: one device per GPU; here one process per GPU): alone it spawns torch.distributed.run with N
+    ranks; under a launcher WORLD_SIZE must agree; fewer visible devices than ranks is an error, never a silent share of GPU 0"""
+    import bench
+    D = bench.launch_decision
+    assert D(1, {}, 1) == ("run", 1) and D(1, {}, 0) == ("run", 1) and D(1, {}, None) == ("run", 1)  # N = 1 on a box without a GPU fails later, loudly, in phx_dev_make
+    assert D(8, {}, 8) == ("spawn", 8) and D(2, {}, 8) == ("spawn", 2)
+    assert D(8, {}, 1)[0] == "error" and "only 1 GPU" in D(8, {}, 1)[1]
+    assert D(8, {"WORLD_SIZE": "8"}, 8) == ("run", 8) and D(4, {"WORLD_SIZE": "4"}, 8) == ("run", 4)
+    assert D(8, {"WORLD_SIZE": "1"}, 8)[0] == "error" and D(1, {"WORLD_SIZE": "8"}, 8)[0] == "error" and D(8, {"WORLD_SIZE": "8"}, 4)[0] == "error"
+    assert D(2, {}, 1, rehearsal=True) == ("spawn", 2) and D(2, {"WORLD_SIZE": "2"}, 1, rehearsal=True) == ("run", 2)
+    assert D(0, {}, 8)[0] == "error"
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """no GPU here: `bench.py --gpus 2` must exit non-zero with a message instead of rendering the frame on whatever device 0 is"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PHX_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4"))
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr

@@ -63,25 +63,40 @@ def test_two_ranks_on_one_gpu_sum_to_the_one_process_film(tmp_path):
 
 @pytest.mark.timeout(600)
 def test_bench_multi_rank_path_rehearsed_on_one_gpu():
-    """bench.py's N > 1 code — torch.distributed.run launch, tile shard by rank, zero-initialised device films, ONE reduce to rank 0,
-    max-over-ranks time, rays summed over ranks, one JSON line from rank 0 — rehearsed with two ranks on this box's one GPU
-    (PHX_BENCH_REHEARSAL=1: both ranks on GPU 0, the reduce on gloo).  The traced rays and the film must be those of the N = 1 run."""
+    """`python bench.py --gpus 2` itself — the launch decision, the torch.distributed.run child, tile shard by rank, zero-initialised
+    device films, ONE reduce to rank 0 inside the bracket, max-over-ranks time, rays summed over ranks, one compact JSON line relayed
+    from rank 0 — rehearsed with two ranks on this box's one GPU (PHX_BENCH_REHEARSAL=1: both ranks on GPU 0, the reduce on gloo).
+    The traced rays and the film must be those of the N = 1 run, and `value` must be the same experiment at both N: one frame in
+    flight, with the two-frames-in-flight throughput beside it."""
     import json
     import subprocess
-    common = ["--triangles", "3000", "--width", "160", "--height", "96", "--spp", "9", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--one-sink"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300)
-    assert one.returncode == 0, one.stderr[-2000:]
-    d1 = json.loads(one.stdout.strip().splitlines()[-1])
-    env = dict(os.environ, PHX_BENCH_REHEARSAL="1")
-    port = 29700 + (os.getpid() % 200)
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + [x if x not in ("1", "0") else {"1": "3", "0": "1"}[x] for x in common],  # 3 steps after 1 warm-up: two frames in flight
-                         capture_output=True, text=True, timeout=300, env=env)
-    assert two.returncode == 0, two.stderr[-2000:]
-    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1  # rank 0 alone prints
-    d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["film_collective"].startswith("reduce") and "rehearsal" in d2 and d2["config"]["frames_in_flight"] == 2
-    assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and d2["config"]["camera_samples_per_step"] == 160 * 96 * 9
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    common = ["--triangles", "3000", "--width", "160", "--height", "96", "--spp", "9", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    recs = {}
+    for n in (1, 2):
+        full = os.path.join(ROOT, "gpurun_out", f"bench_rehearsal_{n}.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--full-json", full] + common, capture_output=True, text=True, timeout=300,
+                           env=dict(env, PHX_BENCH_REHEARSAL="1") if n > 1 else env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096  # rank 0 alone prints, last, compactly
+        recs[n] = (json.loads(lines[0]), json.load(open(full)))
+    (d1, f1), (d2, f2) = recs[1], recs[2]
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["scaling"] == "strong" and "rehearsal" in d2 and "rehearsal" not in d1
+    assert d2["config"]["film_collective"].startswith("reduce") and d1["config"]["film_collective"] == "none"
+    # ONE experiment across N: `value` is one frame in flight at both N, the pipelined rate is its own field at both N
+    assert d1["config"]["frames_in_flight"] == d2["config"]["frames_in_flight"] == 1 and d1["value_definition"] == d2["value_definition"]
+    assert d1["value_two_frames_in_flight"] > 0 and d2["value_two_frames_in_flight"] > 0 and d1["value_host_film"] > 0 and d2["value_host_film"] is None
+    assert d1["config"]["hbm_bytes_per_rank"] > 0 and d2["config"]["hbm_bytes_per_rank"] > 0
+    assert d2["config"]["hbm_bytes_per_rank_two_frames_in_flight"] > d2["config"]["hbm_bytes_per_rank"]
+    assert d2["config"]["rays_per_step"] == d1["config"]["rays_per_step"] and f2["config"]["camera_samples_per_step"] == 160 * 96 * 9
     assert d2["config"]["film_mean"] == d1["config"]["film_mean"] and d2["config"]["film_finite"]
     assert d2["roofline"]["frac"] is None and d2["cpu_baseline"] is None  # reported at N = 1 only
+    assert d1["roofline"]["kernel"] == "k_trace" and d1["roofline"]["avg_launch_ms"] > 0 and d1["roofline"]["stream_GBps"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_launched_with_a_mismatched_world_fails():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

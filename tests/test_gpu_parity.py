@@ -715,8 +715,54 @@ def test_full_size_properties(xpu, orc):
     # the north-star tolerance and the ray counts differ by at most a few rays in millions
     ref0, ost0 = orc.Oracle(sc, spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=16)
     assert max_pixel_l2(film, ref0) < L2_TOL
+    d0 = film[..., :3].astype(np.float64) - ref0[..., :3].astype(np.float64)
+    assert int((np.sqrt((d0 * d0).sum(-1)) > L2_TOL).sum()) == 0  # pixels above the gate under the REFERENCE's tie rule: 0 on this frame (README: 1 / 18 on others)
     for k in ("rays_closest", "rays_shadow", "rays_masked"):
         assert abs(st[k] - ost0[k]) <= 4, (k, st[k], ost0[k])
+
+
+def test_baseline_config_1_at_its_real_size(xpu, orc):
+    """BASELINE.json configs[0]: the Cornell box (12 triangles, 1 area light), 256x256, 64 spp, depth 9 — the reference's own
+    CPU-runnable case, whole frame, device against oracle: ray counts exact and the film bit for bit under the device's tie rule;
+    under the reference's first-met rule the one exact-tie pixel of this scene (the camera ray through the back wall's diagonal,
+    profiles/r03_zzb_full_parity_cornell.json: L2 4.8e-5) stays below the north-star gate."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.cornell(256, 256)
+    film, st = xpu.render(sc, spp=64, seed=1, native_sink=True)
+    orc.set_tie_rule(1)
+    try:
+        ref, ost = orc.Oracle(sc, spp=64, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=1, threads=16)
+    finally:
+        orc.set_tie_rule(0)
+    assert st["camera_samples"] == ost["camera_samples"] == 256 * 256 * 64
+    for k in ("rays_closest", "rays_shadow", "rays_masked"):
+        assert st[k] == ost[k], k
+    assert max_pixel_l2(film, ref) < L2_TOL and bits_equal(film[..., :3], ref[..., :3]) and film[..., :3].max() > 0.1
+    ref0, _ = orc.Oracle(sc, spp=64, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=1, threads=16)
+    d0 = film[..., :3].astype(np.float64) - ref0[..., :3].astype(np.float64)
+    l2 = np.sqrt((d0 * d0).sum(-1))
+    assert int((l2 > L2_TOL).sum()) == 0 and int((l2 > 0).sum()) <= 2
+
+
+def test_auto_builder_falls_back_to_the_host_when_the_device_build_fails(xpu, orc):
+    """PHX_BVH_AUTO builds on the device; if that build fails (no scratch memory, a tree deeper than its tables) preprocess must
+    not: the host's binned-SAH builder takes over, phx_stats says so, and the film is the same.  An explicit DEVICE_LBVH request
+    still fails loudly.  PHX_TEST_FAIL_DEVICE_BUILD is the test hook that makes build_bvh8_gpu report failure."""
+    import os
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(5000, width=64, height=64)
+    want, wst = xpu.render(sc, spp=4, seed=2)
+    assert wst["bvh_built_on_device"] == 1
+    os.environ["PHX_TEST_FAIL_DEVICE_BUILD"] = "1"
+    try:
+        got, gst = xpu.render(sc, spp=4, seed=2)
+        with pytest.raises(xpu.DeviceError, match="device BVH build"):
+            xpu.render(sc, spp=4, seed=2, bvh_builder="device")
+    finally:
+        del os.environ["PHX_TEST_FAIL_DEVICE_BUILD"]
+    assert gst["bvh_built_on_device"] == 0 and bits_equal(got, want) and gst["rays_closest"] == wst["rays_closest"]
+    again, ast_ = xpu.render(sc, spp=4, seed=2)  # the failure left no sticky HIP error behind
+    assert ast_["bvh_built_on_device"] == 1 and bits_equal(again, want)
 
 
 def test_4k_film_in_several_batches(xpu, orc):
