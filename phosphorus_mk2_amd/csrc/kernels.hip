@@ -173,7 +173,11 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   uint32_t phase = 0;  // wave-uniform: 0 = shadow range, 1 = closest range, 2 = drained
   RayCtx r; r.o = v3(0.f); r.d = v3(0.f); r.idx = r.idy = r.idz = 0.f; r.oct_inv = 0;
   float tbest = 0.f, hu = 0.f, hv = 0.f;
-  uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, th = 0, path = 0;
+  uint32_t htri = 0xffffffffu, hprim = 0, idx = 0, ng_base = 0, ng_hits = 0, path = 0;
+  // triangle group of the lane: tg_base = pool index of the first child of the node the triangles hang below; tg = that node's
+  // valid mask (bits 0..7) | hit leaf slots still to test (8..15); (tq_base, tq) is a second such group, waiting
+  constexpr uint32_t TG_PENDING = 0xff00u;
+  uint32_t tg_base = 0, tg = 0, tq_base = 0, tq = 0;  // tq: the second group (valid | pending << 8), 0 = none
   int sp = 0;
   const float4* __restrict__ ro = pb.ro[q];
   const float4* __restrict__ rd = pb.rd[q];
@@ -252,7 +256,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             tbest = b.w; path = f2u(a.w);
           }
           hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
-          ng_base = 0; ng_hits = 0x80000000u; th = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
+          ng_base = 0; ng_hits = 0x80000000u; tg = 0; tq = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
           any = phase == 0u;
           active = true;
         }
@@ -262,102 +266,117 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     if (!__ballot(active)) break;
 #if PHX_COUNT
     ++cnt_iter;
-    if (__ballot(active && th == 0 && ng_hits > 0x00ffffffu)) ++cnt_nb;
-    cnt_idle += (uint32_t)__popcll(__ballot(!active)); cnt_pend += (uint32_t)__popcll(__ballot(active && th != 0));
+    cnt_idle += (uint32_t)__popcll(__ballot(!active));
 #endif
-#pragma unroll
-    for (int step = 0; step < PHX_STEPS_PER_REFILL; ++step)
-    if (active) {
-      // ---- one node visit
-      if (th == 0 && ng_hits > 0x00ffffffu) {
-        const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
-        const uint32_t rest = ng_hits & ~(1u << bit);
-        if (rest > 0x00ffffffu) {
+    // ---- one node visit.  A lane's node work (ng_base, ng_hits, the stack) and its triangle work (tg_base, tg: the hit leaf
+    // slots of ONE visited node; a second such group waits in the lane's LDS slot) are independent: a lane whose last node left
+    // triangles to test goes on to its next node in the same iteration, and sits the node block out only when both triangle
+    // groups are taken.  (Until round 4 a lane with pending triangles sat out: 8.6 of 64 lanes in every iteration.)  Triangles
+    // are then tested LATER relative to the node visits than in traverse8 — against a tbest that is at most smaller — and the
+    // boxes are culled against a tbest that is at most larger: the lane meets a superset of traverse8's triangles, and the closest
+    // hit with its tie rule does not depend on which superset (bvh8.h).
+    const bool node_ok = active && ng_hits > 0x00ffffffu && (any ? !(tg & TG_PENDING) : tq == 0u);  // an any-hit ray tests what it has first: a hit ends it
 #if PHX_COUNT
-          ++cnt_push[sp < 7 ? sp : 7];
+    if (__ballot(node_ok)) ++cnt_nb;
+    cnt_pend += (uint32_t)__popcll(__ballot(active && !node_ok && (tg & TG_PENDING)));
 #endif
-          // SPILL: the top lds_levels entries of the stack live in LDS, the rare deeper ones in HBM (sc.stack_spill)
-          if (!SPILL || (uint32_t)sp < lds_levels) stack_base[sp * BLOCK] = make_uint2(ng_base, rest);
-          else spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride] = make_uint2(ng_base, rest);
-          ++sp;
-        }
-        const uint32_t slot = (bit - 24u) ^ r.oct_inv;
-        const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
-        uint32_t w[16];
+    if (node_ok) {
+      const uint32_t bit = 31u - (uint32_t)__clz((int)ng_hits);
+      const uint32_t rest = ng_hits & ~(1u << bit);
+      if (rest > 0x00ffffffu) {
 #if PHX_COUNT
-        if (ni < ntop) ++cnt_lds[any ? 1 : 0]; else ++cnt_mem[any ? 1 : 0];
+        ++cnt_push[sp < 7 ? sp : 7];
 #endif
-        // top-of-tree nodelets are staged in LDS: four ds_read_b128 instead of four L1 requests per lane.  The LDS lanes go
-        // first: both groups write the same registers, so the second group waits for the first one's data — a few dozen cycles
-        // for LDS, several hundred for the L1/L2 path if it went first.
-        const bool in_lds = ni < ntop;
-        {
-          const uint4* s4 = top + (in_lds ? ni : 0u) * (PHX_NODE_LDS_BYTES / 16u);  // every lane reads (element 0 when its node is not staged)
+        // SPILL: the top lds_levels entries of the stack live in LDS, the rare deeper ones in HBM (sc.stack_spill)
+        if (!SPILL || (uint32_t)sp < lds_levels) stack_base[sp * BLOCK] = make_uint2(ng_base, rest);
+        else spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride] = make_uint2(ng_base, rest);
+        ++sp;
+      }
+      const uint32_t slot = (bit - 24u) ^ r.oct_inv;
+      const uint32_t ni = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << slot));
+      uint32_t w[16];
+#if PHX_COUNT
+      if (ni < ntop) ++cnt_lds[any ? 1 : 0]; else ++cnt_mem[any ? 1 : 0];
+#endif
+      // top-of-tree nodelets are staged in LDS: four ds_read_b128 instead of four L1 requests per lane.  The LDS lanes go
+      // first: both groups write the same registers, so the second group waits for the first one's data — a few dozen cycles
+      // for LDS, several hundred for the L1/L2 path if it went first.
+      const bool in_lds = ni < ntop;
+      {
+        const uint4* s4 = top + (in_lds ? ni : 0u) * (PHX_NODE_LDS_BYTES / 16u);  // every lane reads (element 0 when its node is not staged)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-        }
-        if (!in_lds) {
-          const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ni * 4u;
+        for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+      }
+      if (!in_lds) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ni * 4u;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-        }
+        for (int k = 0; k < 4; ++k) { const uint4 v = s4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+      }
 #if PHX_PROBE_VMEM
-        // sensitivity probe (never in the product build): PHX_PROBE_VMEM more 16-byte loads per node visit, from the neighbouring element
-        if (!in_lds) {
-          const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)(ni ^ 1u) * 4u;
+      // sensitivity probe (never in the product build): PHX_PROBE_VMEM more 16-byte loads per node visit, from the neighbouring element
+      if (!in_lds) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)(ni ^ 1u) * 4u;
 #pragma unroll
-          for (int k = 0; k < PHX_PROBE_VMEM; ++k) {
+        for (int k = 0; k < PHX_PROBE_VMEM; ++k) {
 #if PHX_PROBE_VMEM_DWORD
-            w[2] ^= s4[k].x & (refill_min >> 31);   // same addresses, a quarter of the bytes
+          w[2] ^= s4[k].x & (refill_min >> 31);   // same addresses, a quarter of the bytes
 #else
-            const uint4 v = s4[k]; w[2] ^= (v.x ^ v.y ^ v.z ^ v.w) & (refill_min >> 31);
+          const uint4 v = s4[k]; w[2] ^= (v.x ^ v.y ^ v.z ^ v.w) & (refill_min >> 31);
 #endif
-          }
         }
+      }
 #endif
 #if PHX_PERM_LUT
-        uint32_t hm = node_hitmask(w, sc.grid, r, tbest, [&](uint32_t m) { return (uint32_t)perm_lut[(r.oct_inv << 8) | m]; });
+      uint32_t hm = node_hitmask(w, sc.grid, r, tbest, [&](uint32_t m) { return (uint32_t)perm_lut[(r.oct_inv << 8) | m]; });
 #else
-        uint32_t hm = node_hitmask(w, sc.grid, r, tbest);
+      uint32_t hm = node_hitmask(w, sc.grid, r, tbest);
 #endif
 #if PHX_PROBE_VALU
-        {  // sensitivity probe (never in the product build): PHX_PROBE_VALU more v_fma_f32 per node visit
-          float x = tbest;
+      {  // sensitivity probe (never in the product build): PHX_PROBE_VALU more v_fma_f32 per node visit
+        float x = tbest;
 #pragma unroll
-          for (int k = 0; k < PHX_PROBE_VALU; ++k) x = __builtin_fmaf(x, 0.99999f, 1.0e-3f);
-          hm ^= f2u(x) & (refill_min >> 31);
-        }
-#endif
-        ng_base = w[3];                // the children of the node just visited: nodelets and triangle records, in slot order
-        ng_hits = hm & 0xff0000ffu;    // pending inner children | valid mask
-        th = (hm >> 16) & 0xffu;       // pending triangles, by slot
+        for (int k = 0; k < PHX_PROBE_VALU; ++k) x = __builtin_fmaf(x, 0.99999f, 1.0e-3f);
+        hm ^= f2u(x) & (refill_min >> 31);
       }
-      // ---- one triangle test (ng_base / the valid byte of ng_hits still belong to the node whose triangles are pending)
-#if PHX_COUNT
-      if (th != 0 && lane == (uint32_t)__ffsll((long long)__ballot(th != 0)) - 1u) ++cnt_tb;
 #endif
-      if (th != 0) {
-        const uint32_t k = 31u - (uint32_t)__clz((int)th);
-        th &= ~(1u << k);
-        const uint32_t ti = ng_base + (uint32_t)__popc(ng_hits & 0xffu & ~(0xffffffffu << k));
-        const uint4* t4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ti * 4u;
-        const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2];  // three of the record's four words: v0, e0, e1, prim
-        TriRec T;
-        T.v0x = u2f(t0.x); T.v0y = u2f(t0.y); T.v0z = u2f(t0.z); T.e0x = u2f(t0.w);
-        T.e0y = u2f(t1.x); T.e0z = u2f(t1.y); T.e1x = u2f(t1.z); T.e1y = u2f(t1.w);
-        T.e1z = u2f(t2.x); T.prim = t2.y;
-        float us, vs, ds;
-#if PHX_COUNT
-        ++cnt_tri[any ? 1 : 0];
-#endif
-        if (mt_intersect(T, r.o, r.d, tbest, hprim, us, vs, ds)) {
-          tbest = ds; hu = us; hv = vs; htri = ti; hprim = T.prim;
-          if (any) active = false;  // occluded: nothing to add
-        }
+      ng_base = w[3];                // the children of the node just visited: nodelets and triangle records, in slot order
+      ng_hits = hm & 0xff0000ffu;    // pending inner children | valid mask
+      const uint32_t tnew = (hm >> 8) & TG_PENDING;  // hit leaf slots of this node -> bits 8..15
+      if (tnew) {
+        const uint32_t g = (hm & 0xffu) | tnew;       // valid mask | pending triangles
+        if (!(tg & TG_PENDING)) { tg_base = w[3]; tg = g; }
+        else { tq_base = w[3]; tq = g; }
       }
-      // ---- pop the next group, or finish the ray
-      if (active && th == 0 && ng_hits <= 0x00ffffffu) {
-        if (sp == 0) {
+    }
+    // ---- one triangle test per lane that has one pending
+    const bool tpend = active && (tg & TG_PENDING);
+#if PHX_COUNT
+    if (__ballot(tpend)) ++cnt_tb;
+#endif
+    if (tpend) {
+      const uint32_t k = 23u - (uint32_t)__clz((int)(tg & TG_PENDING));  // slot of the highest pending triangle (bits 8..15 -> 7..0)
+      tg &= ~(0x100u << k);
+      const uint32_t ti = tg_base + (uint32_t)__popc(tg & 0xffu & ~(0xffffffffu << k));
+      const uint4* t4 = reinterpret_cast<const uint4*>(sc.pool) + (size_t)ti * 4u;
+      const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2];  // three of the record's four words: v0, e0, e1, prim
+      TriRec T;
+      T.v0x = u2f(t0.x); T.v0y = u2f(t0.y); T.v0z = u2f(t0.z); T.e0x = u2f(t0.w);
+      T.e0y = u2f(t1.x); T.e0z = u2f(t1.y); T.e1x = u2f(t1.z); T.e1y = u2f(t1.w);
+      T.e1z = u2f(t2.x); T.prim = t2.y;
+      float us, vs, ds;
+#if PHX_COUNT
+      ++cnt_tri[any ? 1 : 0];
+#endif
+      if (mt_intersect(T, r.o, r.d, tbest, hprim, us, vs, ds)) {
+        tbest = ds; hu = us; hv = vs; htri = ti; hprim = T.prim;
+        if (any) active = false;  // occluded: nothing to add
+      }
+      if (!(tg & TG_PENDING) && tq != 0u) { tg_base = tq_base; tg = tq; tq = 0u; }  // this group is done and another one waits
+    }
+    // ---- pop the next node group; a ray is finished when neither nodes nor triangles are left
+    if (active && ng_hits <= 0x00ffffffu) {
+      if (sp == 0) {
+        if (!(tg & TG_PENDING)) {
           if (any) {  // unoccluded: out += beta * li (spt.hpp:184-186); one shadow ray per path and step
             const float4 cc = pb.sc[idx];
             float4 rr = pb.pr[path];
@@ -367,13 +386,13 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             pb.hit[idx] = make_float4(tbest, hu, hv, u2f(htri));
           }
           active = false;
-        } else {
-          --sp;
-          uint2 e;
-          if (!SPILL || (uint32_t)sp < lds_levels) e = stack_base[sp * BLOCK];
-          else e = spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride];
-          ng_base = e.x; ng_hits = e.y;
         }
+      } else {
+        --sp;
+        uint2 e;
+        if (!SPILL || (uint32_t)sp < lds_levels) e = stack_base[sp * BLOCK];
+        else e = spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride];
+        ng_base = e.x; ng_hits = e.y;
       }
     }
   }
@@ -384,8 +403,8 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     atomicAdd(&pb.stats->tri_tests[k], (unsigned long long)cnt_tri[k]);
   }
   for (int k = 0; k < 8; ++k) if (cnt_push[k]) atomicAdd(&pb.stats->stack_pushes[k], (unsigned long long)cnt_push[k]);
-  if (cnt_tb) atomicAdd(&pb.stats->tri_block_execs, (unsigned long long)cnt_tb);  // counted by the first lane that had a triangle
   if (lane == 0) {
+    atomicAdd(&pb.stats->tri_block_execs, (unsigned long long)cnt_tb);
     atomicAdd(&pb.stats->wave_iters, (unsigned long long)cnt_iter);
     atomicAdd(&pb.stats->node_block_execs, (unsigned long long)cnt_nb);
     atomicAdd(&pb.stats->refills, (unsigned long long)cnt_refill);

@@ -5,7 +5,7 @@ triangle blocks run.  python scripts/count_work.py [--triangles N --width W --he
 import argparse, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PHX_LIB"] = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
+os.environ["PHX_LIB"] = os.environ.get("PHX_COUNT_LIB") or os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
 from phosphorus_mk2_amd import scenes, xpu  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--triangles", type=int, default=100000); p.add_argument("--width", type=int, default=1280); p.add_argument("--height", type=int, default=720)
