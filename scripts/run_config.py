@@ -53,6 +53,6 @@ for _ in range(a.frames):
 rays = st["rays_closest"] + st["rays_shadow"]
 print(json.dumps({"scene": sc.name, "triangles": sc.num_triangles, "film": [a.width, a.height], "spp": a.spp, "rank": a.rank, "world": a.world,
                   "tiles": len(tiles), "scene_gen_s": t_scene, "preprocess_s": t_pre, "frame_s": best, "rays": rays, "Mrays_per_s": rays / best / 1e6,
-                  "builder": a.builder, "bvh_cost_model": st["bvh_cost_model"], "bvh_built_on_device": st["bvh_built_on_device"], "bvh_depth": st["bvh_depth"], "bvh_build_ms": st["bvh_build_ms"], "plan": [st["trace_block"], st["trace_ntop"], st["trace_levels"], st["trace_lds_levels"], st["trace_waves_per_cu"]], "trace_ms": st["trace_ms"], "primary_ms": st["primary_ms"], "shade_ms": st["shade_ms"], "bvh_MB": st["bvh_bytes"] / 1e6, "film_mean": float(film.data[..., :3].mean()),
+                  "builder": a.builder, "bvh_cost_model": st["bvh_cost_model"], "bvh_built_on_device": st["bvh_built_on_device"], "bvh_depth": st["bvh_depth"], "bvh_build_ms": st["bvh_build_ms"], "plan": [st["trace_block"], st["trace_ntop"], st["trace_levels"], st["trace_lds_levels"], st["trace_waves_per_cu"]], "trace_ms": st["trace_ms"], "primary_ms": st["primary_ms"], "shade_ms": st["shade_ms"], "bvh_MB": st["bvh_bytes"] / 1e6, "film_mean": float(film.data[..., :3].mean()), "film_sha1": __import__("hashlib").sha1(film.data.tobytes()).hexdigest()[:16], "k_trace_ms": st["closest_ms"], "shade_kernel_ms": st["shade_kernel_ms"], "other_ms": st["shade_ms"] - st["shade_kernel_ms"],
                   "finite": bool(np.isfinite(film.data).all())}))
 dev.close()
