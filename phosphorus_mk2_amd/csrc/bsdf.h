@@ -43,6 +43,10 @@ struct DevMaterial {
   DevLobe lobes[8];
 };
 
+#if defined(__HIPCC__)
+typedef const __attribute__((address_space(4))) DevMaterial ConstMat;  // the material table seen through the constant address space
+#endif
+
 // The lobe loops evaluate one of seven models per iteration, chosen by the lobe's type.  Left alone, the compiler hoists every
 // loop-invariant subexpression of EVERY model (the local-frame directions, their sines, cosines, tangents, ...) in front of the loop
 // and keeps them all alive across it: bsdf_f needed 129 VGPRs although its most expensive model needs 36, and the hoisted arithmetic ran
@@ -129,8 +133,8 @@ PHX_HD float fresnel_mix_factor(float ior, const v3& n, const v3& view /* hits.w
 // of kept lobes is what bsdf_t::lobes would be.  Nothing is copied: bsdf_f / bsdf_sample resolve a lobe's weight where they use it
 // (a per-hit copy of the 576-byte material lived in scratch memory: 700 B per lane, and every material read became a flat load).
 // PERHIT = false compiles the resolution out (scenes without such materials).  `view` = hits.wi.
-template <bool PERHIT>
-PHX_HD bool lobe_weight_at_hit(const DevLobe& l, const v3& n, const v3& view, v3& w) {
+template <bool PERHIT, typename LobeT>
+PHX_HD bool lobe_weight_at_hit(const LobeT& l, const v3& n, const v3& view, v3& w) {
   w = v3(l.wx, l.wy, l.wz);
   if (PERHIT && l.fac_mode != 0u) {
     const float fac = fresnel_mix_factor(l.fac_ior, n, view);
@@ -142,7 +146,8 @@ PHX_HD bool lobe_weight_at_hit(const DevLobe& l, const v3& n, const v3& view, v3
 }
 
 // ---- GGX ---------------------------------------------------------------------------------------
-PHX_HD float ggx_D(const DevLobe& p, const v3& v) {
+template <typename LobeT>
+PHX_HD float ggx_D(const LobeT& p, const v3& v) {
   const float tan2 = ts::tan2_theta(v);
   if (isinf(tan2)) return 0.0f;
   const float ax = p.xalpha, ay = p.yalpha;
@@ -152,7 +157,8 @@ PHX_HD float ggx_D(const DevLobe& p, const v3& v) {
   const float e = ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay)) * tan2;
   return (float)(1.0f / (kPiD * (double)ax * (double)ay * (double)cos4 * (double)(1 + e) * (double)(1 + e)));
 }
-PHX_HD float ggx_Lambda(const DevLobe& p, const v3& v) {
+template <typename LobeT>
+PHX_HD float ggx_Lambda(const LobeT& p, const v3& v) {
   const float att = fabsf(ts::tan_theta(v));
   if (isinf(att)) return 0.0f;
   const float ax = p.xalpha, ay = p.yalpha;
@@ -161,7 +167,8 @@ PHX_HD float ggx_Lambda(const DevLobe& p, const v3& v) {
   const float a2t2 = (alpha * att) * (alpha * att);
   return (-1.0f + sqrtf(1.0f + a2t2)) * 0.5f;
 }
-PHX_HD float ggx_G1(const DevLobe& p, const v3& v) { return 1.0f / (1.0f + ggx_Lambda(p, v)); }
+template <typename LobeT>
+PHX_HD float ggx_G1(const LobeT& p, const v3& v) { return 1.0f / (1.0f + ggx_Lambda(p, v)); }
 PHX_HD void ggx_sample_slope(float cos_theta, float& slope_x, float& slope_y, float u, float v) {
   if ((double)cos_theta > .9999) {
     const float r = sqrtf(u / (1 - u));
@@ -187,7 +194,8 @@ PHX_HD void ggx_sample_slope(float cos_theta, float& slope_x, float& slope_y, fl
   const float z = (v * (v * (v * 0.27385f - 0.73369f) + 0.46341f)) / (v * (v * (v * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
   slope_y = S * z * sqrtf(1.0f + slope_x * slope_x);
 }
-PHX_HD v3 ggx_sample(const DevLobe& p, const v3& wi, float& pdf, float u, float v) {
+template <typename LobeT>
+PHX_HD v3 ggx_sample(const LobeT& p, const v3& wi, float& pdf, float u, float v) {
   const float ax = p.xalpha, ay = p.yalpha;
   const v3 stretched = normalize_inplace(v3(ax * wi.x, wi.y, ay * wi.z));
   float slope_x, slope_y;
@@ -214,20 +222,22 @@ PHX_HD float sheen_L(float x, float r) {
   const float xc = powf_(x, c);
   return a / (1 + b * xc) + d * x + e;
 }
-PHX_HD float sheen_D(const DevLobe& p, const v3& v) {
+template <typename LobeT>
+PHX_HD float sheen_D(const LobeT& p, const v3& v) {
   const float st = ts::sin_theta(v);
   const float oor = 1.0f / p.r;
   return (float)((double)((2.0f + oor) * powf_(st, oor)) / (2.0f * kPiD));
 }
-PHX_HD float sheen_Lambda(const DevLobe& p, const v3& v, float L5) {
+template <typename LobeT>
+PHX_HD float sheen_Lambda(const LobeT& p, const v3& v, float L5) {
   const float ct = v.y;
   const float l = (ct < 0.5f) ? sheen_L(ct, p.r) : 2.0f * L5 - sheen_L(1.0f - ct, p.r);
   return expf_(l);
 }
 
 // ---- Cook-Torrance (local-space inputs; SHEEN selects the distribution) -----------------------------
-template <bool SHEEN>
-PHX_HD float ct_f_local(const DevLobe& p, const v3& li, const v3& lo, float L5) {
+template <bool SHEEN, typename LobeT>
+PHX_HD float ct_f_local(const LobeT& p, const v3& li, const v3& lo, float L5) {
   if (!ts::same_hemi(li, lo)) return 0.0f;
   v3 wh = li + lo;
   const float cos_ti = fabsf(li.y), cos_to = fabsf(lo.y);
@@ -243,12 +253,14 @@ PHX_HD float ct_f_local(const DevLobe& p, const v3& li, const v3& lo, float L5) 
   const float f = fresnel_dielectric(dot(lo, whf), 0.5f);
   return d * g * f * (1.0f / (4.0f * cos_ti * cos_to));
 }
-PHX_HD float ct_pdf(const DevLobe& p, const v3& wi_world, const v3& li, const v3& lo) {
+template <typename LobeT>
+PHX_HD float ct_pdf(const LobeT& p, const v3& wi_world, const v3& li, const v3& lo) {
   if (!ts::same_hemi(li, lo)) return 0.0f;
   const v3 wh = normalize_inplace(li + lo);
   return (ggx_D(p, wh) * ggx_G1(p, wi_world) * fabsf(dot(li, wh)) / fabsf(li.y)) / (4.0f * dot(li, wh));
 }
-PHX_HD float ctr_f_local(const DevLobe& p, const v3& li, const v3& lo) {
+template <typename LobeT>
+PHX_HD float ctr_f_local(const LobeT& p, const v3& li, const v3& lo) {
   if (ts::same_hemi(li, lo)) return 0.0f;
   const float eta = li.y > 0.0f ? p.eta : 1.0f / p.eta;
   const float cos_ti = li.y, cos_to = lo.y;
@@ -264,7 +276,8 @@ PHX_HD float ctr_f_local(const DevLobe& p, const v3& li, const v3& lo) {
   return (1.0f - f) * fabsf(d * g * eta * eta * fabsf(dot(lo, wh)) * fabsf(dot(li, wh)) * factor * factor /
                             (cos_ti * cos_to * sqrt_denom * sqrt_denom));
 }
-PHX_HD float ctr_pdf(const DevLobe& p, const v3& wi_world, const v3& wo_world, const v3& li, const v3& lo) {
+template <typename LobeT>
+PHX_HD float ctr_pdf(const LobeT& p, const v3& wi_world, const v3& wo_world, const v3& li, const v3& lo) {
   const float eta = li.y > 0.0f ? p.eta : 1.0f / p.eta;
   if ((double)dot(wo_world, wi_world) > 0.0) return 0.0f;
   const v3 wh = normalize_inplace(li + lo * eta);
@@ -272,7 +285,8 @@ PHX_HD float ctr_pdf(const DevLobe& p, const v3& wi_world, const v3& wo_world, c
   const float dwh_dwi = fabsf(eta * eta * dot(lo, wh)) / sqrt_denom * sqrt_denom;
   return (ggx_D(p, wh) * wh.y) * dwh_dwi;
 }
-PHX_HD float oren_nayar_f_local(const DevLobe& p, const v3& li, const v3& lo) {
+template <typename LobeT>
+PHX_HD float oren_nayar_f_local(const LobeT& p, const v3& li, const v3& lo) {
   const float cos_theta_i = fabsf(li.y), cos_theta_o = fabsf(lo.y);
   const float sin_theta_i = ts::sin_theta(li), sin_theta_o = ts::sin_theta(lo);
   float max_cos = 0.0f;
@@ -292,8 +306,8 @@ PHX_HD float oren_nayar_f_local(const DevLobe& p, const v3& li, const v3& lo) {
 // eval() of src/bsdf.cpp:29-107: value (grey) and pdf of lobe p for the world-space pair (wi, wo)
 // DIFFUSE_ONLY: every lobe of every material is Lambert (decided once per scene on the host); the other
 // lobe models are compiled out, the arithmetic of the diffuse case is the same code.
-template <bool DIFFUSE_ONLY>
-PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3& wi, const v3& wo, float L5, float& pdf) {
+template <bool DIFFUSE_ONLY, typename LobeT>
+PHX_HD float lobe_eval(const LobeT& p, const v3& n, const Frame& fr, const v3& wi, const v3& wo, float L5, float& pdf) {
   switch (DIFFUSE_ONLY ? (uint32_t)L_DIFFUSE : p.type) {
     case L_DIFFUSE:
       pdf = (float)((double)dot(n, wi) * kInvPiD);
@@ -320,8 +334,10 @@ PHX_HD float lobe_eval(const DevLobe& p, const v3& n, const Frame& fr, const v3&
 // MAXL = 1: the caller guarantees num_lobes <= 1; every lobe index is then the constant 0, so a material assembled in registers
 // (k_shade<2>: DevMatLite) never has to be addressed dynamically.  Same statements, same order, same results.
 // The tangent frame of the hit is the caller's (one per hit, shared with bsdf_sample).  wo = hits.wi (the view direction).
-template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
-PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const Frame& fr, const v3& wi, const v3& wo) {
+// MatT: DevMaterial, or the same struct in the constant address space (PHX_CONST_MAT: a wave-uniform address is then read through the
+// scalar cache into SGPRs — k_shade_g's material-uniform waves).
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false, typename MatT>
+PHX_HD v3 bsdf_f(const MatT& m, const v3& n, const Frame& fr, const v3& wi, const v3& wo) {
   v3 out(0.0f);
   if (m.num_lobes == 0) return out;
   const float atl = dot(n, wi);
@@ -329,7 +345,7 @@ PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const Frame& fr, const v3& w
   const uint32_t nl = MAXL == 1 ? 1u : m.num_lobes;
 #pragma nounroll
   for (uint32_t i = 0; i < nl; ++i) {
-    const DevLobe& p = m.lobes[MAXL == 1 ? 0u : i];
+    const auto& p = m.lobes[MAXL == 1 ? 0u : i];
     v3 w;
     if (!lobe_weight_at_hit<PERHIT>(p, n, wo, w)) continue;
     if ((reflect && (p.flags & B_REFLECT)) || (!reflect && (p.flags & B_TRANSMIT))) {
@@ -343,14 +359,14 @@ PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const Frame& fr, const v3& w
   }
   return out;
 }
-template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
-PHX_HD v3 bsdf_f(const DevMaterial& m, const v3& n, const v3& wi, const v3& wo) { return bsdf_f<DIFFUSE_ONLY, MAXL, PERHIT>(m, n, Frame(n), wi, wo); }
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false, typename MatT>
+PHX_HD v3 bsdf_f(const MatT& m, const v3& n, const v3& wi, const v3& wo) { return bsdf_f<DIFFUSE_ONLY, MAXL, PERHIT>(m, n, Frame(n), wi, wo); }
 
 // bsdf_t::sample, src/bsdf.cpp:133-248.  Returns f (already weighted); pdf == 0 terminates.  wi = hits.wi (the view direction).
 // PERHIT: the lobes of the hit are the baked lobes whose resolved weight is not all zero, in table order (lobe_weight_at_hit):
 // `keep` has a bit per baked lobe, `lobes` counts them, and the sampled index picks the index-th KEPT lobe.
-template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
-PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, const Frame& fr, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false, typename MatT>
+PHX_HD v3 bsdf_sample(const MatT& m, const v3& n, const Frame& fr, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
   pdf = 0.0f; sample_flags = 0; wo = v3(0.0f);
   uint32_t keep = 0xffu, lobes = MAXL == 1 ? (m.num_lobes ? 1u : 0u) : m.num_lobes;
   if (PERHIT && m.per_hit) {
@@ -372,7 +388,7 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, const Frame& fr, float 
     for (uint32_t i = 0; i < m.num_lobes; ++i)
       if (keep & (1u << i)) { if (seen == index) chosen = i; ++seen; }
   }
-  const DevLobe& p = m.lobes[MAXL == 1 ? 0u : chosen];
+  const auto& p = m.lobes[MAXL == 1 ? 0u : chosen];
   float res = 0.0f;
   bool pdf_set = false;
   switch (DIFFUSE_ONLY ? (uint32_t)L_DIFFUSE : p.type) {
@@ -465,7 +481,7 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, const Frame& fr, float 
   int matched = 1;
 #pragma nounroll
   for (uint32_t i = 0; MAXL > 1 && i < m.num_lobes; ++i) {
-    const DevLobe& q = m.lobes[i];
+    const auto& q = m.lobes[i];
     if (i != chosen && (keep & (1u << i)) && ((p.flags & q.flags) == q.flags)) {
       const bool reflect = dot(n, wi) * dot(n, wo) > 0.0f;
       if ((reflect && (q.flags & B_REFLECT)) || (!reflect && (q.flags & B_TRANSMIT))) {
@@ -485,8 +501,8 @@ PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, const Frame& fr, float 
   sample_flags = p.flags;
   return result;
 }
-template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false>
-PHX_HD v3 bsdf_sample(const DevMaterial& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
+template <bool DIFFUSE_ONLY = false, int MAXL = 8, bool PERHIT = false, typename MatT>
+PHX_HD v3 bsdf_sample(const MatT& m, const v3& n, float u1, float u2, const v3& wi, v3& wo, float& pdf, uint32_t& sample_flags) {
   return bsdf_sample<DIFFUSE_ONLY, MAXL, PERHIT>(m, n, Frame(n), u1, u2, wi, wo, pdf, sample_flags);
 }
 

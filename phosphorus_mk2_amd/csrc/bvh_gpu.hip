@@ -190,6 +190,9 @@ __global__ void __launch_bounds__(GB) k_fit(int n, const uint32_t* __restrict__ 
   while (p != 0xffffffffu) {
     if (wrote) stores_done();
     if (atomicAdd(&flags[p], 1u) == 0u) return;  // first arrival: the sibling subtree is not finished yet
+    // The loads below are relaxed, like the add: nothing in the memory model orders them behind it.  The hardware cannot run ahead of the
+    // branch on the add's result (in-order issue); this keeps the COMPILER from hoisting them above the add.
+    asm volatile("" ::: "memory");
     const Box6 a = load_box(&nbox[left[p]]), b = load_box(&nbox[right[p]]);
     Box6 m;
     for (int x = 0; x < 3; ++x) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }

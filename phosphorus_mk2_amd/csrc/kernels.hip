@@ -887,6 +887,26 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_SHADE_ITEMS_G 8
 #endif
 #define PHX_SHADE_BUCKETS 64  /* sort key = material mod 64; then the misses; slots past the end of the queue go last */
+#ifndef PHX_SCALAR_F
+#define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
+#endif
+#ifndef PHX_SCALAR_S
+#define PHX_SCALAR_S 0  /* bsdf_sample picks its lobe per lane: through the scalar path it is 2-3 % slower (profiles/r04_j_shade_scalar_ab.log) */
+#endif
+// The lanes that reach a closure evaluation, one distinct material of the wave at a time (after the window's sort by material most
+// waves hold one): the material's index is made wave-uniform (v_readlane), its recipe is addressed in the CONSTANT address space, and
+// every read with a uniform address — the lobe loops of bsdf_f and bsdf_sample — becomes an s_load into SGPRs instead of a
+// vector load into 64 copies (round 3 made the address uniform without the address space: the compiler cannot prove the table is
+// read-only then and keeps the vector loads; profiles/r03_v_unimat_ab.log).  `body` runs under `mine`; `cm` is the ConstMat&.
+#define PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, body)                                                                      \
+  for (unsigned long long todo_ = __ballot(true); todo_ != 0ull;) {                                                           \
+    uint32_t m0_ = (uint32_t)__builtin_amdgcn_readlane((int)(mat), (int)(__ffsll((long long)todo_) - 1));                     \
+    const bool mine_ = (mat) == m0_;                                                                                          \
+    /* inside `mine_` the optimiser knows mat == m0_ and would address the table with the per-lane register: hide the SGPR */ \
+    asm volatile("" : "+s"(m0_));                                                                                             \
+    if (mine_) { ConstMat& cm = *((ConstMat*)(sc.materials) + m0_); body; }                                                    \
+    todo_ &= ~__ballot(mine_);                                                                                                \
+  }
 template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
@@ -938,7 +958,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       bool alive = false, want_shadow = false, hit_surface = false;
       uint32_t path = 0, depth = 0, key = 0;
       v3 p, n, wo, beta;
-      const DevMaterial* mp = nullptr;
+      uint32_t mat = 0;  // the hit's material: an INDEX — bsdf_f / bsdf_sample read the recipe through the scalar cache, one distinct material of the wave at a time
       if (live) {
         float4 a, b, bd;
         const float4 h = pb.hit[i];
@@ -969,9 +989,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           p = o + d * h.x;            // hits.p = p + wi*d
           wo = -d;                    // hits.wi = -wi
           n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
-          mp = &sc.materials[pm & 0x7fffffffu];  // material_t::evaluate (material.cpp:419-458): the closure recipe at this hit
+          mat = pm & 0x7fffffffu;  // material_t::evaluate (material.cpp:419-458): the closure recipe at this hit
           if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
-          if (depth == 0 || specular) { add_e = v3(mp->ex, mp->ey, mp->ez); add_rad = true; }  // spt.hpp:177-179
+          if (depth == 0 || specular) { const DevMaterial& m = sc.materials[mat]; add_e = v3(m.ex, m.ey, m.ez); add_rad = true; }  // spt.hpp:177-179
         } else {
           // miss: environment lighting (deferred_shading_kernel.hpp:65-70, spt.hpp:199-202); the slot is MASKED|SHADOW in the
           // reference's shadow stream (spt.hpp:138-141): rays_masked = rays_closest - rays_shadow
@@ -1022,7 +1042,12 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           sh_d = v3(sh_d.x * oolen, sh_d.y * oolen, sh_d.z * oolen);
           if (sdot(n, sh_d) >= 0.0f) {
             // li(), spt.hpp:212-255 — evaluated before the occlusion test; k_trace adds it if the ray is unoccluded
-            const v3 f = bsdf_f<false, 8, PERHIT>(*mp, n, fr, sh_d, wo);
+#if PHX_SCALAR_F
+            v3 f(0.0f);
+            PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, f = (bsdf_f<false, 8, PERHIT>(cm, n, fr, sh_d, wo)));
+#else
+            const v3 f = bsdf_f<false, 8, PERHIT>(sc.materials[mat], n, fr, sh_d, wo);
+#endif
             // the light's record again (L1-resident), behind an empty asm so that the first read is not kept alive across bsdf_f
             asm volatile("" : "+v"(l), "+v"(lt));
             const DevLight& L = sc.lights[l];
@@ -1054,7 +1079,13 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           if (alive) {
             const uint32_t b1 = (depth - 1u) * DIMS_PER_STEP;
             float pdf; uint32_t fl;
-            const v3 f = bsdf_sample<false, 8, PERHIT>(*mp, n, fr, draw_f32(key, b1 + DIM_BSDF_U), draw_f32(key, b1 + DIM_BSDF_V), wo, nxt_d, pdf, fl);
+            const float u1 = draw_f32(key, b1 + DIM_BSDF_U), u2 = draw_f32(key, b1 + DIM_BSDF_V);
+#if PHX_SCALAR_S
+            v3 f(0.0f);
+            PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, f = (bsdf_sample<false, 8, PERHIT>(cm, n, fr, u1, u2, wo, nxt_d, pdf, fl)));
+#else
+            const v3 f = bsdf_sample<false, 8, PERHIT>(sc.materials[mat], n, fr, u1, u2, wo, nxt_d, pdf, fl);
+#endif
             if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) {
               alive = false;
             } else {
