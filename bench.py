@@ -295,7 +295,7 @@ def roofline(acc, steps, work, tag, ref_visits):
     return roof
 
 
-# algorithmic bytes per shaded queue entry in the device's layout (DESIGN.md section 2.2): in — hit 16, ray 32, path state 16,
+# algorithmic bytes per shaded queue entry in the device's layout (DESIGN.md section 2): in — hit 16, ray 32, path state 16,
 # triangle record 64 (one 64-B element of the pool); out — next ray 32 + path state 16 for a survivor, 48 for an NEE ray
 SHADE_BYTES_IN, SHADE_BYTES_SURVIVOR, SHADE_BYTES_NEE = 16 + 32 + 16 + 64, 32 + 16, 48
 

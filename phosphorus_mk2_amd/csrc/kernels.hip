@@ -133,7 +133,7 @@ struct LdsStack {
 // (try-lock in LDS, re-check under the lock); waves that lose the race go on traversing and ask again at their next refill.
 // Sixteen waves of one CU then work on neighbouring pixels, and the global cursor takes 1/16 of the atomics.
 // (Round 2 also carried a static XCD-aware split of the queues and per-wave global chunks; both lost to this scheme on every
-// workload and were removed in round 3 — the history is in DESIGN.md section 3.)
+// workload and were removed in round 3 — the history is in EXPERIMENTS.md, Part B section 3.)
 #ifndef PHX_WG_CHUNKS
 #define PHX_WG_CHUNKS 16u  /* chunks in a workgroup's range (fewer when the queue is too short to give every workgroup four ranges) */
 #endif
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(PHX_BLOCK) k_trace_rays(DevScene sc, uint32_t 
 // distances in another order, so the two differ by roundings, which 2^-16 of the distance on both ends is there to cover (node_hit8
 // itself pads by 2^-20).  The lanes then meet a superset of the triangles they meet in k_trace, and the closest hit with its
 // lowest-primitive tie rule does not depend on which superset (bvh8.h); that the films are identical bit for bit is tested, not assumed
-// (DESIGN.md section 4).  A wave whose rays do not share a direction octant (a pixel on one of the film's axes) falls back to the
+// (EXPERIMENTS.md Part B section 4).  A wave whose rays do not share a direction octant (a pixel on one of the film's axes) falls back to the
 // per-lane walk of bvh8.h.
 // wave-wide min / max through DPP (four shifts inside the rows of 16, two row broadcasts; the result lands in lane 63): 13 instructions,
 // where six __shfl_xor rounds would be twelve trips through the LDS crossbar

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON the GPU box: the tuning knobs of DESIGN.md section 7 against the defaults, on the bench frame (100 k) and the 1 M soup
+# Run ON the GPU box: the tuning knobs of EXPERIMENTS.md Part B section 7 against the defaults, on the bench frame (100 k) and the 1 M soup
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 run() { # label, env assignments...
   label=$1; shift
