@@ -55,7 +55,9 @@ struct DevScene {
 // counters (x CNT_STRIDE words): [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity); [4],[5] chunk cursors
 // every counter on its own 128-byte line: the queue-length counters take one atomic per k_shade workgroup and one address (line)
 // sustains ~90 atomics/us — two counters on one line halve what each gets
-enum { CNT_STRIDE = 32, CNT_SHADOW = 2 * CNT_STRIDE, CNT_CURSOR = 4 * CNT_STRIDE, CNT_WORDS = 6 * CNT_STRIDE };
+// [4 + p * CNT_SEGS + s]: the range cursor of queue p (0 shadow, 1 closest) for SEGMENT s of the queue — the queue is cut in CNT_SEGS equal
+// parts, one per XCD (workgroup ids go round the XCDs: id & 7), so that an XCD's L2 serves one part of the image
+enum { CNT_STRIDE = 32, CNT_SHADOW = 2 * CNT_STRIDE, CNT_CURSOR = 4 * CNT_STRIDE, CNT_SEGS = 8, CNT_WORDS = (4 + 2 * CNT_SEGS) * CNT_STRIDE };
 struct DevStats {
   unsigned long long rays_closest, rays_shadow, rays_masked, camera_samples;
   // instrumented build only (-DPHX_COUNT=1, `make variant NAME=count`): traversal work, [0] closest-hit rays, [1] shadow rays

@@ -94,12 +94,16 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers
   { float t = d.x * M[2]; t = fmaf(d.y, M[6], t); w.z = fmaf(d.z, M[10], t); }
 }
 
+__device__ __forceinline__ void zero_cursors(uint32_t* counters) {
+#pragma unroll
+  for (uint32_t k = 0; k < 2u * CNT_SEGS; ++k) counters[CNT_CURSOR + k * CNT_STRIDE] = 0;
+}
 // start of a pass: queue 0 "holds" the num_pixels x num_samples camera rays (state_t::reset, spt.hpp:39-49, is implicit:
 // the first k_shade writes beta, depth and radiance of every path without reading them)
 __global__ void k_begin_pass(PassBuffers pb, uint32_t num_samples) {
   const uint32_t npaths = pb.num_pixels * num_samples;
   pb.counters[0] = npaths; pb.counters[CNT_STRIDE] = 0; pb.counters[CNT_SHADOW] = 0; pb.counters[CNT_SHADOW + CNT_STRIDE] = 0;
-  pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0;
+  zero_cursors(pb.counters);
   atomicAdd(&pb.stats->camera_samples, (unsigned long long)npaths);
 }
 
@@ -136,6 +140,9 @@ struct LdsStack {
 // workload and were removed in round 3 — the history is in EXPERIMENTS.md, Part B section 3.)
 #ifndef PHX_WG_CHUNKS
 #define PHX_WG_CHUNKS 16u  /* chunks in a workgroup's range (fewer when the queue is too short to give every workgroup four ranges) */
+#endif
+#ifndef PHX_XCD_SEGMENTS
+#define PHX_XCD_SEGMENTS 1  /* a workgroup takes its ranges from its XCD's eighth of the queue first */
 #endif
 #ifndef PHX_SPILL_FROM_LEVELS
 #define PHX_SPILL_FROM_LEVELS 10u  /* trees with this many stack levels or more keep only PHX_SPILL_LDS_LEVELS of them in LDS */
@@ -217,10 +224,25 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
               else if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) st = 2;
               else {
                 const uint32_t cwg = phase == 0u ? dq.r0 : dq.r1;
-                const uint32_t nb = atomicAdd(&dq.cursor[phase * CNT_STRIDE], cwg) + gridDim.x * cwg;
+#if PHX_XCD_SEGMENTS
+                // the next range of this XCD's segment of the queue; when that is used up, of the next segment that has one (cursor[8 + phase])
+                uint32_t nb = qn, seg_end = qn, sgm = cursor[8 + phase];
+                for (uint32_t tries = 0; tries < CNT_SEGS; ++tries, sgm = (sgm + 1u) & (CNT_SEGS - 1u)) {
+                  const uint32_t lo_s = (uint32_t)((unsigned long long)qn * sgm / CNT_SEGS), hi_s = (uint32_t)((unsigned long long)qn * (sgm + 1u) / CNT_SEGS);
+                  const uint32_t homes = (gridDim.x + CNT_SEGS - 1u - sgm) / CNT_SEGS;  // workgroups whose first range lies in this segment
+                  const unsigned long long at = (unsigned long long)lo_s + (unsigned long long)homes * cwg + atomicAdd(&dq.cursor[(phase * CNT_SEGS + sgm) * CNT_STRIDE], cwg);
+                  if (at < hi_s) { nb = (uint32_t)at; seg_end = hi_s; break; }
+                }
+                cursor[8 + phase] = sgm;
+                if (nb >= seg_end) { __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); st = 2; }
+                else {
+                  const uint32_t end = min(nb + cwg, seg_end);
+#else
+                const uint32_t nb = atomicAdd(&dq.cursor[phase * CNT_SEGS * CNT_STRIDE], cwg) + gridDim.x * cwg;
                 if (nb >= qn) { __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); st = 2; }
                 else {
                   const uint32_t end = min(nb + cwg, qn);
+#endif
                   got_lo = nb; got_hi = min(nb + c, end); st = 0;  // the fetching wave keeps the range's first chunk
                   __hip_atomic_store(pack, (unsigned long long)(nb + c) | ((unsigned long long)end << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -423,7 +445,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 //   and the global cursor sees one returning atomic per 1024 rays instead of one per chunk (which the wave has to wait for:
 //   with per-wave global chunks 512 rays were the optimum, 64-ray chunks were atomic-bound).  A wave
 //   drains once per launch, not once per slice, and a slow image region is shared by everyone.
-// Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][8 cursor words][2 KB octant table].
+// Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][12 cursor words][2 KB octant table].
 template <int BLOCK, bool SPILL = false>
 __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
                                                  uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t target_chunks) {
@@ -431,7 +453,7 @@ __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb,
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
   uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
-  uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 8);  // PHX_PERM_LUT: 8 octants x 256 masks
+  uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 12);  // PHX_PERM_LUT: 8 octants x 256 masks (cursor: 12 words)
   const uint32_t n_closest = do_closest ? pb.counters[q * CNT_STRIDE] : 0u;
   const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq * CNT_STRIDE] : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -455,7 +477,14 @@ __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb,
     unsigned long long* pack = reinterpret_cast<unsigned long long*>(cursor);
     for (uint32_t p = 0; p < 2u; ++p) {
       const uint32_t cwg = p == 0u ? dq.r0 : dq.r1, qn = p == 0u ? n_shadow : n_closest;
+#if PHX_XCD_SEGMENTS
+      const uint32_t sgm = blockIdx.x & (CNT_SEGS - 1u), kth = blockIdx.x / CNT_SEGS;  // the kth range of this XCD's segment
+      const uint32_t lo_s = (uint32_t)((unsigned long long)qn * sgm / CNT_SEGS), hi_s = (uint32_t)((unsigned long long)qn * (sgm + 1u) / CNT_SEGS);
+      const uint32_t lo = (uint32_t)min((unsigned long long)lo_s + (unsigned long long)kth * cwg, (unsigned long long)hi_s), hi = min(lo + cwg, hi_s);
+      cursor[8 + p] = sgm;
+#else
       const uint32_t lo = min(blockIdx.x * cwg, qn), hi = min(lo + cwg, qn);
+#endif
       pack[p] = (unsigned long long)lo | ((unsigned long long)hi << 32);
       cursor[4 + p] = 0u; cursor[6 + p] = 0u;
     }
@@ -713,7 +742,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   const uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
-  if (i == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0; }  // the next k_trace pulls its chunks from here
+  if (i == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
   // One block per workgroup, grid sized for the queue's capacity.  (A fixed grid walking the queue in a loop — what k_shade_g does —
   // costs this kernel its occupancy: whatever is loop-invariant gets hoisted and held in registers, 51-61 VGPRs become 73-82, and
   // 1024-thread workgroups need <= 64 to run two per CU.)
@@ -915,7 +944,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
   __shared__ uint16_t perm[WINDOW];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { pb.counters[CNT_CURSOR] = 0; pb.counters[CNT_CURSOR + CNT_STRIDE] = 0; }  // the next k_trace pulls its chunks from here
+  if (blockIdx.x == 0 && threadIdx.x == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
   for (uint32_t base = blockIdx.x * WINDOW; base < count; base += gridDim.x * WINDOW) {
     // ---- counting sort of the window by material, through LDS
     if (threadIdx.x < NB + 2) bucket[threadIdx.x] = 0;
@@ -1268,11 +1297,11 @@ TracePlan trace_plan(const DevScene& sc) {
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
     uint32_t ntop_req = E.ntop_env;
     if (!ntop_req) {
-      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.lds_levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.lds_levels * blk * 8u + 48u + (PHX_PERM_LUT ? 2048u : 0u);
       ntop_req = share > stacks + 9u * PHX_NODE_LDS_BYTES ? (share - stacks) / PHX_NODE_LDS_BYTES : 9u;
     }
     ntop_out = std::min(ntop_req, sc.num_elems);
-    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.lds_levels * blk * 8u + 32u + (PHX_PERM_LUT ? 2048u : 0u);
+    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.lds_levels * blk * 8u + 48u + (PHX_PERM_LUT ? 2048u : 0u);
     return std::min(160u * 1024u / lds_out, 2048u / blk);
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
