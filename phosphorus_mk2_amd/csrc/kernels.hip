@@ -599,6 +599,8 @@ __global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves
     atomicAdd(&pb.stats->rays_closest, (unsigned long long)npaths);
   }
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+  // (Dealing the workgroups to the XCDs in bands of the image — XCD x the x-th eighth of the packets — is SLOWER here: 3.35 -> 3.76 ms,
+  // profiles/r04_o_xcd_primary_ab.log: bands of the image cost differently, and a plain grid has no way to steal.)
   const uint32_t base = (blockIdx.x * (PHX_PRIMARY_BLOCK / 64) + wave) * (64u * RPL);
   if (base >= npaths) return;
   uint32_t idx[RPL];
