@@ -57,7 +57,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level par
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth (MI355X_MICROARCH.md, L2)
 CLOCK_HZ = 2.4e9        # max clock
 CUS = 256
-L1_ADDR_PER_CLK_CU = 1.7  # measured ceiling of the vector L1: lane addresses per clock and CU (scripts/micro/l1_gather.hip)
+L1_ADDR_PER_CLK_CU = 1.7  # measured ceiling of the vector L1 for an L1-RESIDENT table: lane addresses per clock and CU (scripts/micro/l1_gather.hip)
+# the same gather over larger tables (profiles/r04_l_pair_help.log, r04_m_l1_gather.log): the rate a uniform gather over a pool of the tree's size reaches
+GATHER_PER_CLK_CU_BY_TABLE = {"16 KB (L1-resident)": 1.67, "2.4 MB (inside one XCD's 4 MB L2)": 1.36, "7.7 MB (the 100 k soup's pool)": 0.81, "77 MB (the 1 M soup's pool)": 0.38}
 COUNT_LIB = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_count.so")
 
 
@@ -226,7 +228,8 @@ def capture_diagnostics(cap, src, kernel, units_in_capture):
         a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / t
         D["vector_l1"] = {"achieved": a / 1e9, "peak": L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ / 1e9, "unit": "G lane addresses/s",
                           "frac": a / (L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ), "l1_hit_rate": e.get("l1_hit_rate"),
-                          "ta_busy_frac": e.get("ta_busy_frac"), "td_busy_frac": e.get("td_busy_frac")}
+                          "ta_busy_frac": e.get("ta_busy_frac"), "td_busy_frac": e.get("td_busy_frac"),
+                          "uniform_gather_lane_addresses_per_clk_cu_by_table": GATHER_PER_CLK_CU_BY_TABLE}
     if "TCP_TCC_READ_REQ_sum" in c:
         a = c["TCP_TCC_READ_REQ_sum"] * 64.0 / t
         D["l2"] = {"achieved": a / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": a / 1e9 / L2_PEAK_GBS, "l2_hit_rate": e.get("l2_hit_rate")}
