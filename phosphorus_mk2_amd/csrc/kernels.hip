@@ -1073,12 +1073,12 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           sh_d = v3(sh_d.x * oolen, sh_d.y * oolen, sh_d.z * oolen);
           if (sdot(n, sh_d) >= 0.0f) {
             // li(), spt.hpp:212-255 — evaluated before the occlusion test; k_trace adds it if the ray is unoccluded
-#if PHX_SCALAR_F
             v3 f(0.0f);
-            PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, f = (bsdf_f<false, 8, PERHIT>(cm, n, fr, sh_d, wo)));
-#else
-            const v3 f = bsdf_f<false, 8, PERHIT>(sc.materials[mat], n, fr, sh_d, wo);
-#endif
+            if constexpr (PHX_SCALAR_F && !PERHIT) {  // (with per-hit closure weights the uniform path costs the kernel 16 B of scratch)
+              PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, f = (bsdf_f<false, 8, PERHIT>(cm, n, fr, sh_d, wo)));
+            } else {
+              f = bsdf_f<false, 8, PERHIT>(sc.materials[mat], n, fr, sh_d, wo);
+            }
             // the light's record again (L1-resident), behind an empty asm so that the first read is not kept alive across bsdf_f
             asm volatile("" : "+v"(l), "+v"(lt));
             const DevLight& L = sc.lights[l];
