@@ -100,3 +100,25 @@ def test_bench_launched_with_a_mismatched_world_fails():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.timeout(600)
+def test_bench_rccl_path_at_world_one():
+    """`bench.py --force-dist`: the N > 1 code with the REAL backend (nccl = RCCL) at world size 1 — process group on the device,
+    zero-initialised device film, the synchronous film reduce inside the bracket, the asynchronous one in the two-frames-in-flight
+    pass, max / sum over ranks on the device — is what one GPU can exercise of the RCCL path.  Same rays and film as the plain run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "PHX_BENCH_REHEARSAL")}
+    env["MASTER_ADDR"] = "127.0.0.1"; env["MASTER_PORT"] = str(29900 + (os.getpid() % 90))
+    common = ["--triangles", "3000", "--width", "160", "--height", "96", "--spp", "9", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--full-json", os.path.join(ROOT, "gpurun_out", "bench_force_dist.json")]
+    recs = []
+    for extra in ([], ["--force-dist"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        recs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    plain, forced = recs
+    assert forced["n_gpus"] == 1 and forced["config"]["film_collective"].startswith("reduce") and plain["config"]["film_collective"] == "none"
+    assert forced["config"]["rays_per_step"] == plain["config"]["rays_per_step"] and forced["config"]["film_mean"] == plain["config"]["film_mean"]
+    assert forced["value"] > 0 and forced["value_two_frames_in_flight"] > 0 and forced["value_host_film"] is None
