@@ -258,7 +258,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
           } else if (st == 0u) {
             dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)got_lo, (int)leader));
             dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)got_hi, (int)leader));
-          } else if (__ballot(active) == 0ull) { __builtin_amdgcn_s_sleep(4); continue; }  // nothing to do but wait for the fetching wave
+          } else if (__ballot(active) == 0ull) { __builtin_amdgcn_s_sleep(4); continue; }  // nothing to do but wait for the fetching wave (the watchdog counts these sleeps too: a separate counter for them cost 2 % of the kernel, profiles/r04_t_spin_ab.log)
         }
         if (phase >= 2u) { hi = 0; base = 0; }
         else {

@@ -765,6 +765,32 @@ def test_auto_builder_falls_back_to_the_host_when_the_device_build_fails(xpu, or
     assert ast_["bvh_built_on_device"] == 1 and bits_equal(again, want)
 
 
+def test_watchdog_fails_the_frame_instead_of_hanging(xpu, orc):
+    """every k_trace wave reaches its exit: a wave that iterates longer than PHX_TRACE_WATCHDOG leaves its loop and raises
+    DevStats::watchdog, and phx_dev_join reports the frame as failed (PHX_ERR_DEVICE) — never a hang that takes the GPU down.
+    libphx_hip_wd.so is the same library built with a watchdog of 8 iterations (__graft_entry__.build): any real frame trips it.
+    Afterwards the device is intact: the product library renders the oracle's film.  (The per-lane fallback walks of
+    k_trace_primary and k_trace_rays are plain bounded tree walks and carry no watchdog.)"""
+    import os, subprocess, sys
+    from conftest import ROOT
+    from phosphorus_mk2_amd import scenes
+    wd = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_wd.so")
+    assert os.path.exists(wd), "build() makes the watchdog twin"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from phosphorus_mk2_amd import scenes, xpu\n"
+            "try:\n"
+            "    xpu.render(scenes.soup(3000, width=64, height=64), spp=4, seed=2)\n"
+            "    print('RENDERED')\n"
+            "except xpu.DeviceError as e:\n"
+            "    print('FAILED:', e)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, PHX_LIB=wd))
+    assert r.returncode == 0 and "FAILED:" in r.stdout and "watchdog" in r.stdout and "RENDERED" not in r.stdout, (r.stdout, r.stderr[-500:])
+    sc = scenes.soup(3000, width=64, height=64)
+    film, st = xpu.render(sc, spp=4, seed=2)
+    ref, ost = orc.Oracle(sc, spp=4, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=2, threads=8)
+    assert st["rays_closest"] == ost["rays_closest"] and bits_equal(film[..., :3], ref[..., :3])
+
+
 def test_4k_film_in_several_batches(xpu, orc):
     """BASELINE config #4 shape of the film (3840x2160: more pixels than one tile batch holds, so the frame is rendered in
     several batches) with the normals channel on; tiles from every batch are compared with the oracle bit for bit."""
