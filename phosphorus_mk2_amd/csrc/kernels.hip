@@ -918,6 +918,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_SHADE_ITEMS_G 8
 #endif
 #define PHX_SHADE_BUCKETS 64  /* sort key = material mod 64; then the misses; slots past the end of the queue go last */
+#ifndef PHX_SHADE_TIMING
+#define PHX_SHADE_TIMING 0  /* probe builds only: s_memtime around k_shade_g's sort phase and shading rounds, summed into DevStats fields the count build uses */
+#endif
 #ifndef PHX_SCALAR_F
 #define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
 #endif
@@ -948,6 +951,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   if (blockIdx.x == 0 && threadIdx.x == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
   for (uint32_t base = blockIdx.x * WINDOW; base < count; base += gridDim.x * WINDOW) {
+#if PHX_SHADE_TIMING
+    const long long tm0 = clock64();
+#endif
     // ---- counting sort of the window by material, through LDS
     if (threadIdx.x < NB + 2) bucket[threadIdx.x] = 0;
     __syncthreads();
@@ -976,6 +982,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) perm[bucket[keys[k]] + ranks[k]] = (uint16_t)(k * BLOCK + threadIdx.x);
     __syncthreads();
+#if PHX_SHADE_TIMING
+    const long long tm1 = clock64();
+#endif
     // ---- the window in sorted order: wave w of round k shades sorted positions [k * BLOCK + 64 w, + 64)
     for (int k = 0; k < ITEMS; ++k) {
       if (base + (uint32_t)k * BLOCK >= count) break;  // workgroup-uniform: the slots past the end of the queue sort behind every live one
@@ -1145,6 +1154,12 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         }
       }
     }
+#if PHX_SHADE_TIMING
+    if ((threadIdx.x & 63u) == 0u) {  // probe build only: cycles of the sort phase / of the shading rounds, per wave
+      const long long tm2 = clock64();
+      atomicAdd(&pb.stats->wave_iters, (unsigned long long)(tm1 - tm0)); atomicAdd(&pb.stats->node_block_execs, (unsigned long long)(tm2 - tm1)); atomicAdd(&pb.stats->refills, 1ull);
+    }
+#endif
     __syncthreads();  // perm and bucket are rewritten by the next window
   }
 }
