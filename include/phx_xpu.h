@@ -67,7 +67,8 @@ typedef struct phx_options {
 /* AUTO = the device builder (LBVH over extended Morton codes + the optimal 8-wide collapse) for every scene with at least 64
  * triangles: 1 M triangles in 12 ms and 10 M in 40 ms against 0.6 s / 7 s of the host's binned-SAH builder, and since round 3 its
  * trees trace as fast or faster on every scene measured (profiles/r03_z_emc_probe.log).  cpu_t::preprocess rebuilds its accelerator
- * on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the interface's cost.  HOST_SAH stays selectable. */
+ * on every call (src/xpu/cpu.cpp:35-44), so the build time is part of the interface's cost.  HOST_SAH stays selectable, and AUTO falls back to it
+ * when the device build fails (phx_stats.bvh_built_on_device = 0); an explicit DEVICE_LBVH request fails with PHX_ERR_DEVICE instead. */
 enum { PHX_BVH_AUTO = 0, PHX_BVH_DEVICE_LBVH = 1, PHX_BVH_HOST_SAH = 2 };
 
 /* ---- scene: what the device reads through scene_t (src/scene.hpp:14-50) --------------- */
