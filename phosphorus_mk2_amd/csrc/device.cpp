@@ -134,6 +134,19 @@ struct phx_device {
     for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes();
     return b;
   }
+  // paths in flight this device may carry: up to 256 M (about 43 GB of queues + state: sized for 288 GB of HBM), but never more than 60 % of
+  // what the device has free right now plus what this object already holds for queues (another device object, torch or RCCL may share the GPU)
+  uint64_t path_budget(size_t path_bytes) const {
+    uint64_t budget = 256ull << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      size_t held = 0;
+      for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n) * sizeof(float4);
+      held += (hit.n + so.n + sd.n + sc.n + pb.n + pr.n + pn.n) * sizeof(float4);
+      budget = std::min<uint64_t>(budget, (uint64_t)((double)(free_b + held) * 0.6) / path_bytes);
+    }
+    return budget;
+  }
   int run_frame();
   int render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit);
 };
@@ -650,8 +663,13 @@ int phx_device::run_frame() {
   }
   if ((rc = jitter.upload(jit))) return rc;
 
-  // drain the shared tile queue in batches (cpu.cpp:233-234 pulls one tile at a time)
-  const uint64_t pixel_cap = 8u << 20;  // pixels per batch
+  // drain the shared tile queue in batches (cpu.cpp:233-234 pulls one tile at a time).  A batch holds as many pixels as can carry ALL
+  // their samples in one pass (P x spp <= the path budget, at most 8 M pixels): path ids are pixel-major, so a pass with every sample of a
+  // pixel keeps the 64 lanes of a wave — and the 256 rays of a camera-ray packet — on ONE pixel.  (Round 3 took 8 M pixels whatever the spp:
+  // the 3840x2160, 256-spp frame of BASELINE config 4 went through as 8 passes of 32 samples; as 8 batches of 256 samples it is 6.8 %
+  // faster — camera rays 67.9 -> 36.0 ms, k_trace -4 %: profiles/r04_v_batch_probe.log.)
+  const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
+  const uint64_t pixel_cap = std::min<uint64_t>(8u << 20, std::max<uint64_t>(path_budget(path_bytes) / std::max(1u, opt.samples_per_pixel), 64u << 10));
   for (;;) {
     std::vector<phx_tile> tiles;
     uint64_t px = 0;
@@ -705,16 +723,9 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     // more than 60 % of what the device has free right now (another device object, torch or RCCL may share the GPU).  Deep
     // bounces keep only a few percent of the paths alive, so many samples per pass are what keeps late launches full; the spp
     // range is then split into equal passes.
-    uint64_t budget = 256ull << 20;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      size_t held = 0;  // what this device already holds for queues is reusable
-      for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n) * sizeof(float4);
-      held += (hit.n + so.n + sd.n + sc.n + pb.n + pr.n + pn.n) * sizeof(float4);
-      budget = std::min<uint64_t>(budget, (uint64_t)((double)(free_b + held) * 0.6) / path_bytes);
-    }
-    budget = std::max<uint64_t>(budget, P);
-    const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / P, 0x7ffffff0ull / P));
+    const uint64_t budget = std::max<uint64_t>(path_budget(path_bytes), P);
+    // (1/16 of slack: the batch that run_frame sized for all of its samples overshoots its pixel cap by up to one tile)
+    const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((budget + budget / 16) / P, 0x7ffffff0ull / P));
     const uint32_t npasses = (spp + smax - 1) / smax;
     S = (spp + npasses - 1) / npasses;
   }
