@@ -134,10 +134,11 @@ struct phx_device {
     for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes();
     return b;
   }
-  // paths in flight this device may carry: up to 256 M (about 43 GB of queues + state: sized for 288 GB of HBM), but never more than 60 % of
+  // paths in flight this device may carry: up to 512 M (about 86 GB of queues + state: sized for 288 GB of HBM), but never more than 60 % of
   // what the device has free right now plus what this object already holds for queues (another device object, torch or RCCL may share the GPU)
   uint64_t path_budget(size_t path_bytes) const {
-    uint64_t budget = 256ull << 20;
+    static const uint64_t cap_m = [] { const char* v = std::getenv("PHX_PATH_BUDGET_M"); const long x = v ? std::atol(v) : 0; return x >= 1 && x <= 1536 ? (uint64_t)x : 512ull; }();  // knob: millions of paths (128 / 256 / 512: config 4 on one GPU 6 987 / 7 182 / 7 314 Mrays/s, profiles/r04_x_budget.log)
+    uint64_t budget = cap_m << 20;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       size_t held = 0;
@@ -719,10 +720,9 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
   uint32_t S = opt.samples_in_flight;
   if (S == 0) {
-    // paths in flight: up to 256 M (about 43 GB of queues + state: sized for 288 GB of HBM; measured +3.5 % over 128 M), but never
-    // more than 60 % of what the device has free right now (another device object, torch or RCCL may share the GPU).  Deep
-    // bounces keep only a few percent of the paths alive, so many samples per pass are what keeps late launches full; the spp
-    // range is then split into equal passes.
+    // paths in flight: the device's budget (path_budget: up to 512 M paths).  Deep bounces keep only a few percent of the paths alive, so
+    // many paths per pass are what keeps late launches full; a batch that cannot carry all its samples at once splits the spp range
+    // into equal passes.
     const uint64_t budget = std::max<uint64_t>(path_budget(path_bytes), P);
     // (1/16 of slack: the batch that run_frame sized for all of its samples overshoots its pixel cap by up to one tile)
     const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((budget + budget / 16) / P, 0x7ffffff0ull / P));
