@@ -10,6 +10,7 @@
 #include "bvh_gpu.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -680,6 +681,16 @@ int phx_device::run_frame() {
       tiles.push_back(t); px += (uint64_t)t.w * t.h;
     }
     if (tiles.empty()) break;
+    {
+      // the batch's tiles in Morton order of their film position: path ids are pixel-major, so the batch's queue — and with it each
+      // XCD's eighth of it (k_trace's segments) — covers a compact block of the film instead of a row of tiles 3840 pixels wide
+      static const bool morton = [] { const char* v = std::getenv("PHX_TILE_MORTON"); return v ? std::atoi(v) != 0 : true; }();
+      if (morton) {
+        auto spread = [](uint32_t v) { v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
+        auto key = [&](const phx_tile& t) { return spread(t.x >> 5) | (spread(t.y >> 5) << 1); };
+        std::stable_sort(tiles.begin(), tiles.end(), [&](const phx_tile& a, const phx_tile& b) { return key(a) < key(b); });
+      }
+    }
     if ((rc = render_batch(tiles, jit))) return rc;
     stats.tiles += tiles.size();
   }
