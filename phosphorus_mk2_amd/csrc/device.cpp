@@ -96,6 +96,7 @@ struct phx_device {
   // pass buffers
   DevBuf<float4> ro[2], rd[2], hit, so, sd, sc, pb, pr, pn;
   DevBuf<uint32_t> counters; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
+  uint64_t jitter_seed = 0; uint32_t jitter_spp = 0;  // what the jitter table on the device was made for
   float* h_acc = nullptr; size_t h_acc_n = 0;  // pinned staging for add_tile
   std::vector<phx_tile> pix_xy_tiles;          // the tiles pix_xy currently describes
 
@@ -137,17 +138,20 @@ struct phx_device {
   }
   // paths in flight this device may carry: up to 512 M (about 86 GB of queues + state: sized for 288 GB of HBM), but never more than 60 % of
   // what the device has free right now plus what this object already holds for queues (another device object, torch or RCCL may share the GPU)
+  mutable uint64_t budget_bytes = 0;  // hipMemGetInfo costs ~0.1 ms a call: asked once per preprocess, not twice per frame
   uint64_t path_budget(size_t path_bytes) const {
     static const uint64_t cap_m = [] { const char* v = std::getenv("PHX_PATH_BUDGET_M"); const long x = v ? std::atol(v) : 0; return x >= 1 && x <= 1536 ? (uint64_t)x : 512ull; }();  // knob: millions of paths (128 / 256 / 512: config 4 on one GPU 6 987 / 7 182 / 7 314 Mrays/s, profiles/r04_x_budget.log)
-    uint64_t budget = cap_m << 20;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      size_t held = 0;
-      for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n) * sizeof(float4);
-      held += (hit.n + so.n + sd.n + sc.n + pb.n + pr.n + pn.n) * sizeof(float4);
-      budget = std::min<uint64_t>(budget, (uint64_t)((double)(free_b + held) * 0.6) / path_bytes);
+    if (!budget_bytes) {
+      budget_bytes = ~0ull;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        size_t held = 0;
+        for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n) * sizeof(float4);
+        held += (hit.n + so.n + sd.n + sc.n + pb.n + pr.n + pn.n) * sizeof(float4);
+        budget_bytes = (uint64_t)((double)(free_b + held) * 0.6);
+      }
     }
-    return budget;
+    return std::min<uint64_t>(cap_m << 20, budget_bytes / path_bytes);
   }
   int run_frame();
   int render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit);
@@ -458,6 +462,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     if ((rc = d->d_spill.alloc((size_t)d->plan.spill_threads * (d->plan.levels - d->plan.lds_levels)))) return rc;
     sc.stack_spill = d->d_spill.p; sc.spill_stride = d->plan.spill_threads;
   }
+  d->budget_bytes = 0;  // the next frame asks the device again how much memory is free
   d->preprocessed = true;
   return PHX_OK;
 }
@@ -663,7 +668,10 @@ int phx_device::run_frame() {
       }
     }
   }
-  if ((rc = jitter.upload(jit))) return rc;
+  if (jitter_seed != frame.sampler_seed || jitter_spp != spp || !jitter.p) {  // a frame loop presents the same seed again and again
+    if ((rc = jitter.upload(jit))) return rc;
+    jitter_seed = frame.sampler_seed; jitter_spp = spp;
+  }
 
   // drain the shared tile queue in batches (cpu.cpp:233-234 pulls one tile at a time).  A batch holds as many pixels as can carry ALL
   // their samples in one pass (P x spp <= the path budget, at most 8 M pixels): path ids are pixel-major, so a pass with every sample of a
