@@ -282,6 +282,12 @@ int phx_dev_bsdf_sample(phx_device* dev, uint32_t material, uint32_t n_items, co
                         const float* wi, const float* u2, float* wo_out, float* f_out,
                         float* pdf_out, uint32_t* flags_out);
 
+/* The acceleration structure of the preprocessed scene as the traversal kernels read it (a parity hook: the tests check that every box the
+ * device builder stored contains what hangs below it).  Copies min(capacity, size) bytes of the pool of 64-byte elements (csrc/bvh8.h:
+ * element 0 = root nodelet) to `out`, stores the pool's size in *bytes and the per-scene grid of the nodelets' origins in grid6
+ * (lo.xyz, cell.xyz; origin = fma(i, cell, lo)). */
+int phx_dev_copy_bvh(phx_device* dev, void* out, uint64_t capacity, uint64_t* bytes, float* grid6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,7 +108,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "phx_discover", "phx_dev_make", "phx_dev_preprocess", "phx_dev_start", "phx_dev_join", "phx_dev_destroy",
     "phx_last_error", "phx_dev_get_stats", "phx_tiles_make", "phx_tiles_next", "phx_tiles_count", "phx_tiles_reset",
-    "phx_tiles_free", "phx_dev_trace", "phx_dev_bsdf_f", "phx_dev_bsdf_sample",
+    "phx_tiles_free", "phx_dev_trace", "phx_dev_bsdf_f", "phx_dev_bsdf_sample", "phx_dev_copy_bvh",
 ]
 
 
@@ -133,4 +133,5 @@ def declare(lib):
     lib.phx_dev_bsdf_f.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, f32p, f32p, f32p]; lib.phx_dev_bsdf_f.restype = C.c_int
     lib.phx_dev_bsdf_sample.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, f32p, f32p, f32p, f32p, f32p, u32p]
     lib.phx_dev_bsdf_sample.restype = C.c_int
+    lib.phx_dev_copy_bvh.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), f32p]; lib.phx_dev_copy_bvh.restype = C.c_int
     return lib

@@ -636,6 +636,18 @@ static int dev_bsdf_sample_impl(phx_device* d, uint32_t material, uint32_t n, co
   return PHX_OK;
 }
 
+int phx_dev_copy_bvh(phx_device* d, void* out, uint64_t capacity, uint64_t* bytes, float* grid6) {
+  if (!d || !d->preprocessed) return fail(PHX_ERR_STATE, "copy_bvh before preprocess");
+  if (!bytes) return fail(PHX_ERR_ARG, "copy_bvh: null size pointer");
+  DeviceScope on(d->hip_device);
+  if (!on.ok) return fail(PHX_ERR_DEVICE, "hipSetDevice failed");
+  *bytes = d->bvh_bytes;
+  if (grid6) for (int a = 0; a < 3; ++a) { grid6[a] = d->scene.grid.lo[a]; grid6[3 + a] = d->scene.grid.cell[a]; }
+  const uint64_t n = std::min<uint64_t>(capacity, d->bvh_bytes);
+  if (out && n) HIPCHK(hipMemcpy(out, d->d_pool.p, n, hipMemcpyDeviceToHost));
+  return PHX_OK;
+}
+
 }  // extern "C"
 
 // ---- the frame driver ------------------------------------------------------------------------------------

@@ -299,6 +299,14 @@ class HipDevice:
                                                         fl.ctypes.data_as(abi.u32p)), "phx_dev_bsdf_sample")
         return wo, f, pdf, fl
 
+    def bvh_pool(self):
+        """the acceleration structure as the kernels read it: (uint32 array [elements, 16], grid lo[3], grid cell[3]) — phx_dev_copy_bvh"""
+        n = C.c_uint64(0); grid = np.zeros(6, np.float32)
+        _check(self._lib, self._lib.phx_dev_copy_bvh(self._h, None, 0, C.byref(n), grid.ctypes.data_as(abi.f32p)), "phx_dev_copy_bvh")
+        pool = np.zeros(n.value // 4, np.uint32)
+        _check(self._lib, self._lib.phx_dev_copy_bvh(self._h, pool.ctypes.data_as(C.c_void_p), n.value, C.byref(n), grid.ctypes.data_as(abi.f32p)), "phx_dev_copy_bvh")
+        return pool.reshape(-1, 16), grid[:3].copy(), grid[3:].copy()
+
     def close(self):
         if self._h:
             self._lib.phx_dev_destroy(self._h)

@@ -315,6 +315,71 @@ def test_device_built_bvh_matches_host_built(xpu, orc, name, n):
     assert max_pixel_l2(devb, ref) < L2_TOL and bits_equal(devb[..., :3], ref[..., :3])
 
 
+def _check_bvh_containment(pool, glo, gcell):
+    """walk the 8-wide tree breadth first (numpy, a level at a time), then bottom-up: the box a nodelet stores for a child must contain
+    every TRIANGLE that hangs below that child (a child's own stored boxes live on the child's grid and may stick out of the parent's
+    box by a grid unit of the child: the invariant is about the geometry).  -> (nodelets, triangles, deepest level)"""
+    u8 = pool.view(np.uint8).reshape(-1, 64)
+    n_el = len(pool)
+    true_lo = np.full((n_el, 3), np.inf); true_hi = np.full((n_el, 3), -np.inf)
+    slot = np.arange(8)
+    levels = []
+    level = np.array([0], np.int64)
+    nodes = tris = 0
+    while len(level):
+        w = pool[level].astype(np.uint64)
+        ix = w[:, 0] & 0x3ffff; iy = ((w[:, 0] >> 18) | (w[:, 1] << 14)) & 0x3ffff; iz = (w[:, 1] >> 4) & 0x3ffff
+        valid = ((w[:, 1] >> 22) & 0xff).astype(np.uint32); imask = (w[:, 2] >> 24).astype(np.uint32); base = w[:, 3].astype(np.int64)
+        org = np.stack([ix, iy, iz], 1).astype(np.float64) * gcell.astype(np.float64) + glo.astype(np.float64)  # fma(i, cell, lo) up to one rounding
+        org = org.astype(np.float32).astype(np.float64)
+        e = np.stack([w[:, 2] & 0xff, (w[:, 2] >> 8) & 0xff, (w[:, 2] >> 16) & 0xff], 1).astype(np.int64)
+        scale = np.ldexp(1.0, e - 127)
+        q = u8[level][:, 16:].reshape(-1, 6, 8).astype(np.float64)  # rows: lox loy loz hix hiy hiz, columns: slots
+        lo = org[:, :, None] + q[:, 0:3, :] * scale[:, :, None]; hi = org[:, :, None] + q[:, 3:6, :] * scale[:, :, None]  # [n, axis, slot]
+        vbit = ((valid[:, None] >> slot) & 1).astype(bool); ibit = ((imask[:, None] >> slot) & 1).astype(bool)
+        assert not (ibit & ~vbit).any()
+        child = base[:, None] + np.cumsum(vbit, 1) - vbit
+        assert child[vbit].max() < n_el
+        tn, ts = np.nonzero(vbit & ~ibit)
+        if len(tn):  # triangle records: a, a + e0, a + e1 (the builder's fp32 v0, e0, e1: b and c up to a rounding)
+            ti = child[tn, ts]
+            rec = pool[ti].view(np.float32).astype(np.float64)
+            a3 = rec[:, 0:3]; b3 = a3 + rec[:, 3:6]; c3 = a3 + rec[:, 6:9]
+            true_lo[ti] = np.minimum(np.minimum(a3, b3), c3); true_hi[ti] = np.maximum(np.maximum(a3, b3), c3)
+            tris += len(tn)
+        nodes += len(level)
+        levels.append((level, child, vbit, lo, hi))
+        cn, cs = np.nonzero(ibit)
+        level = child[cn, cs]
+    for level, child, vbit, lo, hi in reversed(levels):  # bottom-up: true bounds of every subtree, checked against the stored boxes
+        cl = np.where(vbit[:, :, None], true_lo[np.where(vbit, child, 0)], np.inf); ch = np.where(vbit[:, :, None], true_hi[np.where(vbit, child, 0)], -np.inf)  # [n, slot, axis]
+        assert np.isfinite(cl[vbit]).all() and np.isfinite(ch[vbit]).all()
+        eps = 1e-5 * (1.0 + np.abs(cl) + np.abs(ch))
+        slo = np.transpose(lo, (0, 2, 1)); shi = np.transpose(hi, (0, 2, 1))
+        ok = (slo <= cl + eps) & (shi >= ch - eps)
+        assert ok[vbit].all(), "geometry sticks out of the box its ancestor stores for it"
+        true_lo[level] = cl.min(1); true_hi[level] = ch.max(1)
+    return nodes, tris, len(levels)
+
+
+@pytest.mark.parametrize("name,n", [("soup", 1000000), ("showroom", 200000)])
+def test_device_built_tree_boxes_contain_their_subtrees(xpu, name, n):
+    """the device builder's bottom-up passes (k_fit, k_collapse_dp: chains hand boxes and costs to one another inside ONE launch through
+    agent-scope stores / loads and an arrival counter, bvh_gpu.hip) under real load: in the finished 8-wide tree every stored box must
+    contain the whole subtree below it — a box read before its sibling chain had written it would not.  Read back through
+    phx_dev_copy_bvh and walked on the host."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(n, width=64, height=64) if name == "soup" else scenes.showroom(n, width=64, height=64)
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=1, paths_per_sample=1, bvh_builder="device"))
+    for _ in range(2):  # twice: the hand-offs are timing dependent
+        dev.preprocess(sc)
+        pool, glo, gcell = dev.bvh_pool()
+        st = dev.stats()
+        nodes, tris, depth = _check_bvh_containment(pool, glo, gcell)
+        assert nodes == st["bvh_nodes"] and tris == st["triangles"] and depth == st["bvh_depth"] and len(pool) == nodes + tris
+    dev.close()
+
+
 def test_device_builder_handoff_under_load(xpu):
     """The bottom-up passes of the device builder (k_fit, k_collapse_dp) hand boxes and sub-costs from chain to chain inside one
     launch with agent-scope stores / loads and no cache maintenance (bvh_gpu.hip: store_handoff / load_handoff).  A stale read there
