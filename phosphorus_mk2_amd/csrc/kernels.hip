@@ -918,6 +918,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_SHADE_ITEMS_G 8
 #endif
 #define PHX_SHADE_BUCKETS 64  /* sort key = material mod 64; then the misses; slots past the end of the queue go last */
+#ifndef PHX_SHADE_KEY_PROBE
+#define PHX_SHADE_KEY_PROBE 0
+#endif
 #ifndef PHX_SHADE_TIMING
 #define PHX_SHADE_TIMING 0  /* probe builds only: s_memtime around k_shade_g's sort phase and shading rounds, summed into DevStats fields the count build uses */
 #endif
@@ -964,7 +967,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       uint32_t key = NB + 1u;
       if (i < count) {
         const uint32_t tri = f2u(pb.hit[i].w);
+#if PHX_SHADE_KEY_PROBE
+        key = tri != 0xffffffffu ? 0u : (uint32_t)NB;  // probe builds only: what the material gather of the sort phase costs (one-material scenes)
+#else
         key = tri != 0xffffffffu ? (sc.tris[tri].material & (NB - 1u)) : (uint32_t)NB;
+#endif
       }
       keys[k] = key;
       ranks[k] = atomicAdd(&bucket[key], 1u);
