@@ -771,9 +771,13 @@ def main(argv=None):
                 out["secondary"] = sec
         else:
             out["cpu_baseline"] = None
-            out["roofline"] = roofline(acc, args.steps, None, workload_tag("soup", args.triangles, W, H, args.depth), None) if world == 1 else {
-                "bound": None, "kernel": "k_trace", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                "note": "roofline and cpu_baseline are reported at N = 1"}
+            if world == 1:
+                out["roofline"] = roofline(acc, args.steps, None, workload_tag("soup", args.triangles, W, H, args.depth), None)
+            else:  # rank 0's own k_trace launches (HIP events of this run): rays per launch, time per launch, compulsory stream bytes per second
+                r0 = roofline(acc, args.steps, None, None, None)
+                out["roofline"] = {**{k: r0[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_ms",
+                                                         "rays_per_launch", "kernel_rays_per_s", "stream_GBps", "stream_frac_of_hbm_peak")},
+                                   "note": "rank 0's share of the frame; the work-based fraction and the counter diagnostics are reported at N = 1"}
         out["config"]["kernel_ms_per_step"] = {**kernel_ms(acc, args.steps), "frame": acc["frame_ms"] / args.steps}
         path = write_full(out, args.full_json)
         print(compact_line(out, path), flush=True)
