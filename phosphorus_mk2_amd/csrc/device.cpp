@@ -95,7 +95,7 @@ struct phx_device {
 
   // pass buffers
   DevBuf<float4> ro[2], rd[2], hit, so, sd, sc, pb, pr, pn;
-  DevBuf<uint32_t> counters; DevBuf<uint32_t> sort_bins; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
+  DevBuf<uint32_t> counters; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
   uint64_t jitter_seed = 0; uint32_t jitter_spp = 0;  // what the jitter table on the device was made for
   float* h_acc = nullptr; size_t h_acc_n = 0;  // pinned staging for add_tile
   std::vector<phx_tile> pix_xy_tiles;          // the tiles pix_xy currently describes
@@ -132,7 +132,7 @@ struct phx_device {
   uint64_t device_bytes() const {
     uint64_t b = d_pool.bytes() + d_prim_material.bytes() + d_prim_normals.bytes() + d_spill.bytes() + d_materials.bytes() + d_mat_lite.bytes() +
                  d_lights.bytes() + d_light_tris.bytes() + hit.bytes() + so.bytes() + sd.bytes() + sc.bytes() + pb.bytes() + pr.bytes() + pn.bytes() +
-                 counters.bytes() + sort_bins.bytes() + dstats.bytes() + pix_xy.bytes() + jitter.bytes() + acc.bytes();
+                 counters.bytes() + dstats.bytes() + pix_xy.bytes() + jitter.bytes() + acc.bytes();
     for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes();
     return b;
   }
@@ -657,7 +657,7 @@ int phx_device::run_frame() {
   std::memset(&stats, 0, sizeof(stats));
   events_used = 0; timed.clear();
   int rc;
-  if ((rc = dstats.alloc(1)) || (rc = counters.alloc(CNT_WORDS)) || (rc = sort_bins.alloc(32768))) return rc;
+  if ((rc = dstats.alloc(1)) || (rc = counters.alloc(CNT_WORDS))) return rc;
   HIPCHK(hipMemsetAsync(dstats.p, 0, sizeof(DevStats), stream));
   HIPCHK(hipMemsetAsync(counters.p, 0, CNT_WORDS * sizeof(uint32_t), stream));
 
@@ -825,12 +825,6 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
       } else if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, 1, cap); }))) return rc;
       if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
       q ^= 1;
-      if (bounce + 1 < opt.path_depth) {  // experiment (PHX_SORT_RAYS): the survivors, sorted by origin cell, land in the other queue buffer
-        static const bool sort_on = std::getenv("PHX_SORT_RAYS") != nullptr;
-        bool sorted = false;
-        if (sort_on && (rc = timed_launch(2, [&]() { sorted = launch_sort_rays(stream, scene, B, q, sort_bins.p, bounce + 1); }))) return rc;
-        if (sorted) q ^= 1;
-      }
     }
     if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;
     if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;

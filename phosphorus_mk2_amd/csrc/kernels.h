@@ -108,8 +108,6 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
 void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, uint32_t npaths, uint32_t sample0, int q, int sq);
 // shades queue q, appends survivors to queue q^1 and NEE rays to shadow queue sq
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays);
-// experiment (PHX_SORT_RAYS): counting sort of ray queue q by origin cell x octant into queue q ^ 1; `bins` = 32768 words; false = off
-bool launch_sort_rays(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t* bins, uint32_t bounce);
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);
 void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width);
 

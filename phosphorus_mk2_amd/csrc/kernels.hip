@@ -1244,67 +1244,6 @@ __global__ void __launch_bounds__(64) k_bsdf_sample(const DevMaterial* mat, uint
   f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z; pdf[i] = p; flags[i] = fl;
 }
 
-// ---- queue-wide ray sort (experiment, PHX_SORT_RAYS=bits per axis; off by default) -------------------------------------------------
-// Closest-hit rays of the deeper bounces start wherever the previous bounce ended: a wave's 64 rays walk 64 unrelated parts of the
-// tree.  A counting sort of the WHOLE queue by the Morton cell of the ray's origin on the scene grid (x the direction octant) puts rays
-// that start in the same region side by side.  Results cannot change: a ray carries its path id, the sampler is keyed by path and
-// sample, and a path has one closest-hit ray and one shadow ray per step, so no two queue entries ever touch the same radiance word.
-// Three launches: histogram of the keys (global atomics), exclusive scan (one workgroup), scatter into the other queue buffer.
-__device__ __forceinline__ uint32_t sort_key(const float4 a, const float4 b, const float3 lo, const float3 inv, uint32_t bits, uint32_t use_oct) {
-  if (bits >= 16u) return (__float_as_uint(a.w) & 0x7fffffffu) >> (bits - 16u);  // probe: key = path id >> shift (restores the pixel-major order)
-  const float top = (float)((1u << bits) - 1u);
-  const uint32_t cx = (uint32_t)fminf(fmaxf((a.x - lo.x) * inv.x, 0.0f), top);
-  const uint32_t cy = (uint32_t)fminf(fmaxf((a.y - lo.y) * inv.y, 0.0f), top);
-  const uint32_t cz = (uint32_t)fminf(fmaxf((a.z - lo.z) * inv.z, 0.0f), top);
-  uint32_t m = 0;
-  for (uint32_t k = 0; k < bits; ++k) m |= (((cx >> k) & 1u) << (3u * k)) | (((cy >> k) & 1u) << (3u * k + 1u)) | (((cz >> k) & 1u) << (3u * k + 2u));
-  if (!use_oct) return m;
-  return (m << 3) | (b.x < 0.0f ? 0u : 4u) | (b.y < 0.0f ? 0u : 2u) | (b.z < 0.0f ? 0u : 1u);
-}
-__global__ void __launch_bounds__(256) k_sort_hist(PassBuffers pb, int q, uint32_t* bins, float3 lo, float3 inv, uint32_t bits, uint32_t use_oct) {
-  const uint32_t n = pb.counters[q * CNT_STRIDE];
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
-    atomicAdd(&bins[sort_key(pb.ro[q][i], pb.rd[q][i], lo, inv, bits, use_oct)], 1u);
-}
-__global__ void __launch_bounds__(1024) k_sort_scan(PassBuffers pb, int q, uint32_t* bins, uint32_t nbins) {
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (nbins + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(lo + per, nbins);
-  uint32_t sum = 0;
-  for (uint32_t k = lo; k < hi; ++k) sum += bins[k];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < 1024u; ++t) { const uint32_t c = part[t]; part[t] = run; run += c; } pb.counters[(q ^ 1) * CNT_STRIDE] = run; }
-  __syncthreads();
-  uint32_t run = part[threadIdx.x];
-  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = bins[k]; bins[k] = run; run += c; }
-}
-__global__ void __launch_bounds__(256) k_sort_scatter(PassBuffers pb, int q, uint32_t* bins, float3 lo, float3 inv, uint32_t bits, uint32_t use_oct) {
-  const uint32_t n = pb.counters[q * CNT_STRIDE];
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const float4 a = pb.ro[q][i], b = pb.rd[q][i];
-    const uint32_t at = atomicAdd(&bins[sort_key(a, b, lo, inv, bits, use_oct)], 1u);
-    pb.ro[q ^ 1][at] = a; pb.rd[q ^ 1][at] = b;
-  }
-}
-// sorts ray queue q into the buffers of queue q ^ 1 (whose counter receives the length); returns false when the experiment is off
-bool launch_sort_rays(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, uint32_t* bins, uint32_t bounce) {
-  static const int bits = [] { const char* v = getenv("PHX_SORT_RAYS"); const int x = v ? atoi(v) : 0; return x < 0 || x > 40 ? 0 : x; }();
-  static const int use_oct = [] { const char* v = getenv("PHX_SORT_OCT"); return v ? atoi(v) : 1; }();
-  static const int from = [] { const char* v = getenv("PHX_SORT_FROM"); return v ? atoi(v) : 1; }();
-  if (bits == 0 || (int)bounce < from) return false;
-  const uint32_t nbins = bits >= 16 ? 32768u : 1u << (3 * bits + (use_oct ? 3 : 0));
-  if (nbins > 32768u) return false;
-  const float span = (float)(1u << (PHX_GRID_BITS - bits));  // grid cells per sort cell
-  const float3 lo = make_float3(sc.grid.lo[0], sc.grid.lo[1], sc.grid.lo[2]);
-  const float3 inv = make_float3(1.0f / (sc.grid.cell[0] * span), 1.0f / (sc.grid.cell[1] * span), 1.0f / (sc.grid.cell[2] * span));
-  (void)hipMemsetAsync(bins, 0, nbins * sizeof(uint32_t), stream);
-  const uint32_t grid = sc.num_cus * 8u;
-  hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, stream, pb, q, bins, lo, inv, (uint32_t)bits, (uint32_t)use_oct);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, stream, pb, q, bins, nbins);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, stream, pb, q, bins, lo, inv, (uint32_t)bits, (uint32_t)use_oct);
-  return true;
-}
-
 // ---- launches ---------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n) { return (n + PHX_BLOCK - 1) / PHX_BLOCK; }
 void launch_begin_pass(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples) {
