@@ -111,7 +111,9 @@ struct phx_device {
   uint64_t paths_in_flight = 0;
   double bvh_cost_model = 0; uint32_t bvh_built_on_device = 0;
   std::vector<hipEvent_t> events; size_t events_used = 0;
-  std::vector<std::pair<size_t, int>> timed;  // (event index of start, kind 0 k_trace / 2 begin-pass, film / 3 shade)
+  struct Timed { size_t begin, end; int kind; };
+  std::vector<Timed> timed;  // (event before, event behind, kind 0 k_trace / 2 begin-pass, film / 3 shade / 4 k_trace_primary)
+  std::chrono::steady_clock::time_point t_start, t_enq, t_sync;  // host timing probe (PHX_HOST_TIMING)
 
   ~phx_device() {
     if (driver.joinable()) driver.join();
@@ -475,6 +477,7 @@ int phx_dev_start(phx_device* d, const phx_frame* f) {
   if (!f->add_tile && !f->device_film && !f->host_film) return fail(PHX_ERR_ARG, "frame without a film sink");
   if (f->primary_components != 3 && f->primary_components != 4) return fail(PHX_ERR_ARG, "primary channel must have 3 or 4 components");
   d->frame = *f;
+  d->t_start = std::chrono::steady_clock::now();
   d->running = true;
   d->frame_status = PHX_OK;
   const int rc = guarded([&]() {
@@ -714,7 +717,9 @@ int phx_device::run_frame() {
     if ((rc = render_batch(tiles, jit))) return rc;
     stats.tiles += tiles.size();
   }
+  t_enq = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(stream));
+  t_sync = std::chrono::steady_clock::now();
   DevStats ds;
   HIPCHK(hipMemcpy(&ds, dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
   stats.camera_samples = ds.camera_samples; stats.rays_closest = ds.rays_closest; stats.rays_shadow = ds.rays_shadow;
@@ -729,14 +734,21 @@ int phx_device::run_frame() {
   if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace: " + std::to_string(ds.watchdog) + " wave(s) hit the iteration watchdog: the frame is incomplete");
   for (auto& te : timed) {
     float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, events[te.first], events[te.first + 1]));
-    if (te.second == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
-    else if (te.second == 4) { stats.primary_ms += ms; stats.primary_launches++; }  // k_trace_primary: the camera rays of a pass
+    HIPCHK(hipEventElapsedTime(&ms, events[te.begin], events[te.end]));
+    if (te.kind == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
+    else if (te.kind == 4) { stats.primary_ms += ms; stats.primary_launches++; }  // k_trace_primary: the camera rays of a pass
     else stats.shade_ms += ms;
-    if (te.second == 3) { stats.shade_kernel_ms += ms; stats.shade_launches++; }
+    if (te.kind == 3) { stats.shade_kernel_ms += ms; stats.shade_launches++; }
   }
   stats.trace_ms = stats.closest_ms + stats.shadow_ms + stats.primary_ms;
   stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  static const bool host_timing = std::getenv("PHX_HOST_TIMING") != nullptr;
+  if (host_timing && events_used >= 2) {
+    float gpu = 0.0f; (void)hipEventElapsedTime(&gpu, events[0], events[events_used - 1]);
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "host timing: start->thread %.3f  thread->sync-begin (enqueue etc.) %.3f  sync wait %.3f  stats %.3f | first..last event on the GPU %.3f ms | start->done %.3f\n",
+                 ms(t_start, t0), ms(t0, t_enq), ms(t_enq, t_sync), ms(t_sync, std::chrono::steady_clock::now()), gpu, ms(t_start, std::chrono::steady_clock::now()));
+  }
   return PHX_OK;
 }
 
@@ -802,13 +814,19 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   B.seed = frame.sampler_seed;
 
   const float inv = 1.0f / (float)(spp * opt.paths_per_sample);  // cpu.cpp:191
+  // One event BETWEEN two launches serves as the end of the first and the start of the second (an event record is a packet of its own in
+  // the queue: 42 of them per pass made the gaps between the 21 launches longer than the launches need).  A launch's time then includes
+  // the few microseconds since the previous kernel ended.
+  long last_end = -1;  // index of the event recorded behind the previous timed launch of this batch
   auto timed_launch = [&](int kind, auto&& fn) -> int {
-    hipEvent_t e0, e1; int r;
-    if ((r = next_event(&e0)) || (r = next_event(&e1))) return r;
-    HIPCHK(hipEventRecord(e0, stream));
+    hipEvent_t e; int r;
+    if (last_end < 0) { if ((r = next_event(&e))) return r; HIPCHK(hipEventRecord(e, stream)); last_end = (long)events_used - 1; }
+    const size_t begin = (size_t)last_end;
     fn();
-    HIPCHK(hipEventRecord(e1, stream));
-    timed.emplace_back(events_used - 2, kind);
+    if ((r = next_event(&e))) return r;
+    HIPCHK(hipEventRecord(e, stream));
+    last_end = (long)events_used - 1;
+    timed.push_back({begin, (size_t)last_end, kind});
     return PHX_OK;
   };
   for (uint32_t s0 = 0; s0 < spp; s0 += S) {
