@@ -181,12 +181,28 @@ def workload_tag(kind, triangles, width, height, depth=9):
             ("zoo", 500000, 1920, 1080): "zoo", ("zoo", 500000, 3840, 2160): "zoo4k"}.get((kind, triangles, width, height))
 
 
+def priced_source_hash():
+    """hash of the bvh8.h functions the roofline prices (scripts/src_hash.py): the tree's, now"""
+    from scripts import src_hash
+    return src_hash.priced_source_hash()
+
+
 def committed_valu_peak():
-    """node tests / triangle tests per second of the chip running k_trace's own arithmetic alone (scripts/micro/valu_mix.hip)"""
+    """node tests / triangle tests per second of the chip running k_trace's own arithmetic alone (scripts/micro/valu_mix.hip)
+    -> (peak dict or None, path, reason it was refused or None).  A peak is only used when it was measured on the sources of THIS
+    tree: the micro-benchmark records the hash of the functions it timed, and a peak without one, or with another, is refused."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_mix.json")))
     if not files:
-        return None, None
-    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+        return None, None, "no profiles/r*_valu_mix.json"
+    peak, src = json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    try:
+        now = priced_source_hash()
+    except Exception as e:  # the sources are part of the repo: this is a broken checkout
+        return None, src, f"cannot hash csrc/bvh8.h ({e})"
+    if peak.get("src_hash") != now:
+        return None, src, (f"stale peak: {src} was measured on node/triangle-test sources with hash {peak.get('src_hash')}, the tree's is {now} "
+                           "(re-run scripts/capture_valu_mix.sh on the GPU box and commit its output)")
+    return peak, src, None
 
 
 def count_work(triangles, width, height, spp, builder):
@@ -221,14 +237,19 @@ def capture_diagnostics(cap, src, kernel, units_in_capture):
     c, n = e["counters"], e["launches"]
     t = kt["total_ms"] * 1e-3 * (n / kt["launches"])  # seconds of the n launches the PMC passes summed over
     D = {"source": src, "kernel_ms_in_capture": kt["total_ms"], "launches_in_capture": kt["launches"], "pmc_launches": n}
+    # per-clock ceilings are priced at the clock the kernel really ran at in the capture (GRBM_GUI_ACTIVE is summed over the 8 XCDs:
+    # cycles / 8 / kernel time; k_trace runs at ~2.2 GHz, not the 2.4 GHz maximum), falling back to the maximum when the capture has no such pass
+    clock = c["GRBM_GUI_ACTIVE"] / 8.0 / t if c.get("GRBM_GUI_ACTIVE") else CLOCK_HZ
+    D["clock_hz"] = clock
+    D["clock_source"] = "GRBM_GUI_ACTIVE / 8 / kernel time of the capture" if c.get("GRBM_GUI_ACTIVE") else "maximum clock (no GRBM_GUI_ACTIVE pass in the capture)"
     if "SQ_INSTS_VALU" in c:
         a = c["SQ_INSTS_VALU"] / t
-        D["valu_issue"] = {"achieved": a / 1e9, "peak": CUS * 4 * CLOCK_HZ / 2 / 1e9, "unit": "G wave-instructions/s", "frac": a / (CUS * 4 * CLOCK_HZ / 2),
+        D["valu_issue"] = {"achieved": a / 1e9, "peak": CUS * 4 * clock / 2 / 1e9, "unit": "G wave-instructions/s", "frac": a / (CUS * 4 * clock / 2),
                            "lane_utilisation": e.get("valu_lane_utilisation"), "wave_cycles_waiting_frac": e.get("wave_cycles_waiting_frac")}
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
         a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / t
-        D["vector_l1"] = {"achieved": a / 1e9, "peak": L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ / 1e9, "unit": "G lane addresses/s",
-                          "frac": a / (L1_ADDR_PER_CLK_CU * CUS * CLOCK_HZ), "l1_hit_rate": e.get("l1_hit_rate"),
+        D["vector_l1"] = {"achieved": a / 1e9, "peak": L1_ADDR_PER_CLK_CU * CUS * clock / 1e9, "unit": "G lane addresses/s",
+                          "frac": a / (L1_ADDR_PER_CLK_CU * CUS * clock), "l1_hit_rate": e.get("l1_hit_rate"),
                           "ta_busy_frac": e.get("ta_busy_frac"), "td_busy_frac": e.get("td_busy_frac"),
                           "uniform_gather_lane_addresses_per_clk_cu_by_table": GATHER_PER_CLK_CU_BY_TABLE}
     if "TCP_TCC_READ_REQ_sum" in c:
@@ -260,7 +281,11 @@ def roofline(acc, steps, work, tag, ref_visits):
     roof["stream_GBps"] = stream_bytes / t_frame / 1e9
     roof["stream_bytes_per_launch"] = stream_bytes * steps / nl
     roof["stream_frac_of_hbm_peak"] = stream_bytes / t_frame / 1e9 / HBM_PEAK_GBS
-    peak, peak_src = committed_valu_peak()
+    peak, peak_src, peak_refused = committed_valu_peak()
+    roof["timing"] = ("HIP events on the device's own stream, ONE event between consecutive launches: a launch's time includes the few "
+                      "microseconds since the previous kernel ended")
+    if work and "error" not in work and not peak:
+        roof["frac_unavailable"] = peak_refused
     if work and "error" not in work and peak:
         nv = sum(work[k]["rays"] * (work[k]["node_visits_lds_per_ray"] + work[k]["node_visits_mem_per_ray"]) for k in ("closest", "shadow"))
         tt = sum(work[k]["rays"] * work[k]["tri_tests_per_ray"] for k in ("closest", "shadow"))
@@ -268,6 +293,7 @@ def roofline(acc, steps, work, tag, ref_visits):
         roof.update({"achieved": nv / t_frame / 1e9, "peak": nv / t_min / 1e9, "frac": t_min / t_frame})
         roof["work"] = {"node_visits_per_frame": nv, "tri_tests_per_frame": tt, "min_alu_ms_per_frame": t_min * 1e3, "k_trace_ms_per_frame": t_frame * 1e3,
                         "peak_node_tests_per_s": peak["node_tests_per_s"], "peak_tri_tests_per_s": peak["tri_tests_per_s"], "peak_source": peak_src,
+                        "peak_src_hash": peak.get("src_hash"), "peak_clock_hz": peak.get("clock_hz"),
                         "lanes_per_node_block": work["wave"]["lanes_per_node_block"], "lanes_per_tri_block": work["wave"]["lanes_per_tri_block"],
                         "what": "node visits + triangle tests of this frame (instrumented build, this run) priced at the chip's rate for k_trace's own "
                                 "arithmetic alone (all 64 lanes active, operands in registers) = minimum ALU time / k_trace time of this run"}
@@ -519,6 +545,10 @@ def compact_roofline(rf):
         out["stream_GBps"] = _r(rf["stream_GBps"])             # compulsory queue bytes / live HIP-event time of this run
     if rf.get("diagnostics"):
         out["counters_from"] = rf["diagnostics"]["source"]
+    if rf.get("frac_unavailable"):
+        out["frac_unavailable"] = rf["frac_unavailable"][:200]
+    if (rf.get("work") or {}).get("peak_source"):
+        out["peak_from"] = rf["work"]["peak_source"]
     return out
 
 

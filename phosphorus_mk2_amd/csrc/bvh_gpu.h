@@ -19,7 +19,10 @@ struct GpuBvh {
 
 // d_abc: 9 floats per primitive (a, b, c) in scene_t::triangles() order, device memory.
 // d_prim_material: per-primitive material word (material | smooth << 31), device memory.
-// Returns 0 on success; on failure writes a message to err and leaves *out empty.
+// Returns 0 on success; on failure writes a message to err and leaves *out empty: BVH_GPU_RECOVERABLE when the cause is one a host
+// build can step around (the builder's scratch or pool did not fit the device's free memory; the tree is deeper than the traversal's
+// tables), 1 for everything else — a HIP error from a launch or a sync, or a builder that lost triangles: bugs, never to be hidden.
+enum { BVH_GPU_RECOVERABLE = 2 };
 int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen);
 
 }  // namespace phx

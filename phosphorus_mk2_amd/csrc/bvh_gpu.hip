@@ -485,7 +485,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   uint32_t* queues = (uint32_t*)dalloc(4 * 4 * (size_t)n);
   uint32_t* counters = (uint32_t*)dalloc(4 * BC_STRIDE * sizeof(uint32_t));
   if (!pbox || !cb || !keys || !keys2 || !vals || !sorted || !left || !right || !parent || !first || !last || !flags || !nbox || !queues || !counters) {
-    std::snprintf(err, errlen, "hipMalloc failed in the device BVH builder"); cleanup(); return 1;
+    std::snprintf(err, errlen, "hipMalloc failed in the device BVH builder"); cleanup(); return BVH_GPU_RECOVERABLE;
   }
   const uint32_t init_cb[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   HCHK(hipMemcpyAsync(cb, init_cb, sizeof(init_cb), hipMemcpyHostToDevice, stream));
@@ -495,7 +495,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   size_t temp_bytes = 0;
   HCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
   void* temp = dalloc(temp_bytes);
-  if (!temp) { std::snprintf(err, errlen, "hipMalloc failed (sort scratch)"); cleanup(); return 1; }
+  if (!temp) { std::snprintf(err, errlen, "hipMalloc failed (sort scratch)"); cleanup(); return BVH_GPU_RECOVERABLE; }
   HCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
   hipLaunchKernelGGL(k_leaf_boxes, g, b, 0, stream, pbox, sorted, (int)n, nbox);
   // (The binary tree is Karras' radix tree over the extended Morton keys.  PLOC — bottom-up merging of the clusters whose union has the
@@ -520,7 +520,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   // output pool: n triangle records + at most n - 1 nodelets (every nodelet has at least two children)
   if (hipMalloc((void**)&pool, sizeof(PoolElem) * 2 * (size_t)n) != hipSuccess) {
     pool = nullptr;
-    std::snprintf(err, errlen, "hipMalloc failed (BVH8 pool)"); cleanup(); return 1;
+    std::snprintf(err, errlen, "hipMalloc failed (BVH8 pool)"); cleanup(); return BVH_GPU_RECOVERABLE;
   }
   uint32_t* qa[2] = {queues, queues + 2 * (size_t)n}; uint32_t* qb[2] = {queues + (size_t)n, queues + 3 * (size_t)n};
   const uint32_t zero_root[2] = {0u, 0u};
@@ -536,7 +536,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   if (!(getenv("PHX_LBVH_COLLAPSE") && atoi(getenv("PHX_LBVH_COLLAPSE")) == 0)) {
     sub = (float*)dalloc(4 * (size_t)n);
     cut = (uint32_t*)dalloc(4 * 8 * (size_t)n); cut_count = (uint8_t*)dalloc((size_t)n);
-    if (!sub || !cut || !cut_count) { std::snprintf(err, errlen, "hipMalloc failed (collapse tables)"); cleanup(); return 1; }
+    if (!sub || !cut || !cut_count) { std::snprintf(err, errlen, "hipMalloc failed (collapse tables)"); cleanup(); return BVH_GPU_RECOVERABLE; }
     HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));  // k_fit is done with its arrival flags
     const float cn = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f;
     hipLaunchKernelGGL(k_collapse_dp, dim3((n + 64 * DP_WAVES - 1) / (64 * DP_WAVES)), dim3(64 * DP_WAVES), 0, stream, (int)n, left, right, parent, nbox, flags, sub, cut, cut_count, cn, 1.0f);
@@ -556,7 +556,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
     cur ^= 1;
     if (count > 0 && depth >= PHX_MAX_BVH_DEPTH) {
       std::snprintf(err, errlen, "tree too deep: more than %d levels (PHX_MAX_BVH_DEPTH, the traversal stack in LDS)", PHX_MAX_BVH_DEPTH);
-      cleanup(); return 1;
+      cleanup(); return BVH_GPU_RECOVERABLE;
     }
   }
   HCHK(hipStreamSynchronize(stream));

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,10 @@
 #include <vector>
 
 using namespace phx;
+
+#ifndef PHX_TEST_HOOKS
+#define PHX_TEST_HOOKS 0  /* 1 only in the twin library libphx_hip_hooks.so (fault injection for the tests); never in the product build */
+#endif
 
 namespace {
 
@@ -102,32 +107,60 @@ struct phx_device {
 
   // frame
   phx_frame frame{};
+  // ONE driver thread per device, kept across frames (cpu_t spawns its workers per frame, src/xpu/cpu.cpp:223-238; here a frame of a rank
+  // of eight lasts 9 ms and a thread start costs 50-70 us of it): phx_dev_start hands it the frame, phx_dev_join waits for `frame_done`
   std::thread driver;
+  std::mutex mu; std::condition_variable cv;
+  bool frame_pending = false, frame_done = false, quit = false;
   bool running = false;
   int frame_status = PHX_OK;
-  std::string frame_error;  // g_error of the driver thread, copied before it exits
+  std::string frame_error;  // g_error of the driver thread, copied when its frame ends
   phx_stats stats{};
   TracePlan plan{};
   uint64_t paths_in_flight = 0;
   double bvh_cost_model = 0; uint32_t bvh_built_on_device = 0;
-  std::vector<hipEvent_t> events; size_t events_used = 0;
-  struct Timed { size_t begin, end; int kind; };
-  std::vector<Timed> timed;  // (event before, event behind, kind 0 k_trace / 2 begin-pass, film / 3 shade / 4 k_trace_primary)
+  struct Timed { size_t begin, end; int kind; };  // (event before, event behind, kind 0 k_trace / 2 begin-pass, film / 3 shade / 4 k_trace_primary)
+  // The launches of a batch — memset, [begin-pass, camera rays, shade, (trace, shade) x (depth - 1), trace, film] per pass, film scatter:
+  // 21 kernels per pass at depth 9, one event between consecutive ones — as ONE hipGraph, captured the first time a batch with these
+  // kernel arguments is met and launched with a single call afterwards (a frame loop presents the same batches again and again).
+  // A graph encodes nothing but (kernel, grid, block, LDS bytes, arguments), so the cache key is a hash of everything those derive from.
+  struct BatchGraph {
+    uint64_t key = 0, last_use = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    std::vector<hipEvent_t> events; size_t events_used = 0;
+    std::vector<Timed> timed;
+  };
+  std::vector<BatchGraph*> graphs;  // at most MAX_GRAPHS, least recently used goes first
+  BatchGraph direct;                // the same launches straight into the stream (PHX_GRAPH=0, or after a capture failed)
+  uint64_t graph_clock = 0; bool graphs_broken = false;
+  enum { MAX_GRAPHS = 16 };
   std::chrono::steady_clock::time_point t_start, t_enq, t_sync;  // host timing probe (PHX_HOST_TIMING)
 
+  static void drop_graph(BatchGraph& g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    for (auto e : g.events) (void)hipEventDestroy(e);
+    g.exec = nullptr; g.graph = nullptr; g.events.clear(); g.events_used = 0; g.timed.clear();
+  }
   ~phx_device() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv.notify_all();
     if (driver.joinable()) driver.join();
-    for (auto e : events) (void)hipEventDestroy(e);
+    for (auto* g : graphs) { drop_graph(*g); delete g; }
+    drop_graph(direct);
     if (h_acc) (void)hipHostFree(h_acc);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
-  int next_event(hipEvent_t* out) {
-    if (events_used == events.size()) {
+  static int next_event(BatchGraph& g, hipEvent_t* out) {
+    if (g.events_used == g.events.size()) {
       hipEvent_t e; HIPCHK(hipEventCreate(&e));
-      events.push_back(e);
+      g.events.push_back(e);
     }
-    *out = events[events_used++];
+    *out = g.events[g.events_used++];
     return PHX_OK;
   }
   // HBM held by this device object (phx_stats::device_bytes)
@@ -155,7 +188,9 @@ struct phx_device {
     }
     return std::min<uint64_t>(cap_m << 20, budget_bytes / path_bytes);
   }
+  void driver_loop();
   int run_frame();
+  int enqueue_batch(BatchGraph& g, const PassBuffers& B0, uint32_t P, uint32_t S, uint32_t xs);
   int render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit);
 };
 
@@ -375,16 +410,28 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
     DevBuf<float> d_abc;
     char msg[256] = {0};
-    const bool force_fail = std::getenv("PHX_TEST_FAIL_DEVICE_BUILD") != nullptr;  // test hook (tests/test_gpu_parity.py), read per call
     rc = d_abc.upload(abc);
-    int brc = rc ? 1 : (force_fail ? (std::snprintf(msg, sizeof(msg), "forced failure (PHX_TEST_FAIL_DEVICE_BUILD)"), 1)
-                                   : build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg)));
+    int brc = rc ? (rc == PHX_ERR_OOM ? (int)BVH_GPU_RECOVERABLE : 1) : 0;
+    if (rc) std::snprintf(msg, sizeof(msg), "%s", g_error.c_str());
+#if PHX_TEST_HOOKS
+    // test hook, compiled into the twin library libphx_hip_hooks.so only (tests/test_gpu_parity.py): makes the device build report a
+    // recoverable or a fatal failure
+    if (const char* how = std::getenv("PHX_TEST_FAIL_DEVICE_BUILD")) {
+      brc = std::strcmp(how, "fatal") == 0 ? 1 : (int)BVH_GPU_RECOVERABLE;
+      std::snprintf(msg, sizeof(msg), "forced %s failure (PHX_TEST_FAIL_DEVICE_BUILD)", brc == 1 ? "fatal" : "recoverable");
+    }
+#endif
+    if (!brc) brc = build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg));
     if (brc) {
-      // An explicit DEVICE_LBVH request fails loudly.  Under AUTO the host's binned-SAH builder handled every scene before the device
-      // builder became the default, so a device build that cannot get its scratch memory (or meets a tree deeper than its tables)
-      // falls back to it: clear the sticky HIP error, build on the host, and say so in phx_stats::bvh_built_on_device.
-      if (builder != PHX_BVH_AUTO) return rc ? rc : fail(PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
-      (void)hipGetLastError();
+      // An explicit DEVICE_LBVH request fails loudly, and so does AUTO when the device builder reports anything but a RECOVERABLE cause
+      // (a HIP error from a launch or a sync, lost triangles: bugs that a silent 0.6-7 s host build would hide).  Under AUTO a device
+      // build that cannot get its scratch memory, or meets a tree deeper than its tables, falls back to the host's binned-SAH builder
+      // — which handled every scene before the device builder became the default — and says so: on stderr, in phx_last_error of this
+      // thread (a successful call leaves the text in place) and in phx_stats::bvh_built_on_device.
+      if (builder != PHX_BVH_AUTO || brc != (int)BVH_GPU_RECOVERABLE) return fail(rc ? rc : PHX_ERR_DEVICE, std::string("device BVH build: ") + msg);
+      (void)hipGetLastError();  // a failed hipMalloc leaves its error behind
+      g_error = std::string("device BVH build fell back to the host builder: ") + msg;
+      std::fprintf(stderr, "libphx_hip: %s\n", g_error.c_str());
       want_host = true;
     }
   }
@@ -478,24 +525,27 @@ int phx_dev_start(phx_device* d, const phx_frame* f) {
   if (f->primary_components != 3 && f->primary_components != 4) return fail(PHX_ERR_ARG, "primary channel must have 3 or 4 components");
   d->frame = *f;
   d->t_start = std::chrono::steady_clock::now();
-  d->running = true;
-  d->frame_status = PHX_OK;
   const int rc = guarded([&]() {
-    d->driver = std::thread([d]() {
-      d->frame_status = guarded([d]() { return d->run_frame(); });
-      d->frame_error = d->frame_status != PHX_OK ? g_error : std::string();
-    });
+    if (!d->driver.joinable()) d->driver = std::thread([d]() { d->driver_loop(); });  // the first frame of this device starts its driver
     return (int)PHX_OK;
   });
-  if (rc != PHX_OK) d->running = false;  // the driver thread could not be created
-  return rc;
+  if (rc != PHX_OK) return rc;  // the driver thread could not be created
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->running = true; d->frame_status = PHX_OK; d->frame_done = false; d->frame_pending = true;
+  }
+  d->cv.notify_all();
+  return PHX_OK;
 }
 
 int phx_dev_join(phx_device* d) {
   if (!d) return fail(PHX_ERR_ARG, "join: null device");
   if (!d->running) return fail(PHX_ERR_STATE, "join without start");
-  d->driver.join();
-  d->running = false;
+  {
+    std::unique_lock<std::mutex> lk(d->mu);
+    d->cv.wait(lk, [d]() { return d->frame_done; });
+    d->running = false;
+  }
   if (d->frame_status != PHX_OK) g_error = d->frame_error;
   return d->frame_status;
 }
@@ -654,11 +704,30 @@ int phx_dev_copy_bvh(phx_device* d, void* out, uint64_t capacity, uint64_t* byte
 }  // extern "C"
 
 // ---- the frame driver ------------------------------------------------------------------------------------
+void phx_device::driver_loop() {
+  (void)hipSetDevice(hip_device);
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [this]() { return frame_pending || quit; });
+      if (quit) return;
+      frame_pending = false;
+    }
+    const int st = guarded([this]() { return run_frame(); });
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      frame_status = st;
+      frame_error = st != PHX_OK ? g_error : std::string();
+      frame_done = true;
+    }
+    cv.notify_all();
+  }
+}
+
 int phx_device::run_frame() {
   HIPCHK(hipSetDevice(hip_device));
   const auto t0 = std::chrono::steady_clock::now();
   std::memset(&stats, 0, sizeof(stats));
-  events_used = 0; timed.clear();
   int rc;
   if ((rc = dstats.alloc(1)) || (rc = counters.alloc(CNT_WORDS))) return rc;
   HIPCHK(hipMemsetAsync(dstats.p, 0, sizeof(DevStats), stream));
@@ -694,7 +763,9 @@ int phx_device::run_frame() {
   // the 3840x2160, 256-spp frame of BASELINE config 4 went through as 8 passes of 32 samples; as 8 batches of 256 samples it is 6.8 %
   // faster — camera rays 67.9 -> 36.0 ms, k_trace -4 %: profiles/r04_v_batch_probe.log.)
   const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
-  const uint64_t pixel_cap = std::min<uint64_t>(8u << 20, std::max<uint64_t>(path_budget(path_bytes) / std::max(1u, opt.samples_per_pixel), 64u << 10));
+  // (divided by the samples a pass will really carry: with an explicit samples_in_flight only P x S paths are ever in flight)
+  const uint32_t pass_samples = std::max(1u, std::min(opt.samples_per_pixel, opt.samples_in_flight ? opt.samples_in_flight : opt.samples_per_pixel));
+  const uint64_t pixel_cap = std::min<uint64_t>(8u << 20, std::max<uint64_t>(path_budget(path_bytes) / pass_samples, 64u << 10));
   for (;;) {
     std::vector<phx_tile> tiles;
     uint64_t px = 0;
@@ -732,22 +803,13 @@ int phx_device::run_frame() {
   stats.primary_packets = ds.primary_packets; stats.primary_fallbacks = ds.primary_fallbacks; stats.primary_node_tests = ds.primary_node_tests;
   stats.primary_tri_tests = ds.primary_tri_tests; stats.primary_tri_lanes_hit = ds.primary_tri_lanes_hit;
   if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace: " + std::to_string(ds.watchdog) + " wave(s) hit the iteration watchdog: the frame is incomplete");
-  for (auto& te : timed) {
-    float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, events[te.begin], events[te.end]));
-    if (te.kind == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
-    else if (te.kind == 4) { stats.primary_ms += ms; stats.primary_launches++; }  // k_trace_primary: the camera rays of a pass
-    else stats.shade_ms += ms;
-    if (te.kind == 3) { stats.shade_kernel_ms += ms; stats.shade_launches++; }
-  }
   stats.trace_ms = stats.closest_ms + stats.shadow_ms + stats.primary_ms;
   stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   static const bool host_timing = std::getenv("PHX_HOST_TIMING") != nullptr;
-  if (host_timing && events_used >= 2) {
-    float gpu = 0.0f; (void)hipEventElapsedTime(&gpu, events[0], events[events_used - 1]);
+  if (host_timing) {
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    std::fprintf(stderr, "host timing: start->thread %.3f  thread->sync-begin (enqueue etc.) %.3f  sync wait %.3f  stats %.3f | first..last event on the GPU %.3f ms | start->done %.3f\n",
-                 ms(t_start, t0), ms(t0, t_enq), ms(t_enq, t_sync), ms(t_sync, std::chrono::steady_clock::now()), gpu, ms(t_start, std::chrono::steady_clock::now()));
+    std::fprintf(stderr, "host timing: start->thread %.3f  thread->sync-begin (enqueue etc.) %.3f  sync wait %.3f  stats %.3f | kernels on the GPU %.3f ms | start->done %.3f\n",
+                 ms(t_start, t0), ms(t0, t_enq), ms(t_enq, t_sync), ms(t_sync, std::chrono::steady_clock::now()), stats.trace_ms + stats.shade_ms, ms(t_start, std::chrono::steady_clock::now()));
   }
   return PHX_OK;
 }
@@ -761,17 +823,22 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   const uint32_t xs = frame.primary_components + (frame.normals_channel ? 3u : 0u);
   // bytes of queues + state per path in flight: ray queues 2 x 32, hit 16, shadow queue 48, path state 32 (+ 16 with normals)
   const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
-  uint32_t S = opt.samples_in_flight;
-  if (S == 0) {
-    // paths in flight: the device's budget (path_budget: up to 512 M paths).  Deep bounces keep only a few percent of the paths alive, so
-    // many paths per pass are what keeps late launches full; a batch that cannot carry all its samples at once splits the spp range
-    // into equal passes.
+  // paths in flight: the device's budget (path_budget: up to 512 M paths).  Deep bounces keep only a few percent of the paths alive, so
+  // many paths per pass are what keeps late launches full; a batch that cannot carry all its samples at once splits the spp range
+  // into equal passes.
+  auto pick_samples = [&]() -> uint32_t {
+    if (opt.samples_in_flight) return opt.samples_in_flight;
     const uint64_t budget = std::max<uint64_t>(path_budget(path_bytes), P);
     // (1/16 of slack: the batch that run_frame sized for all of its samples overshoots its pixel cap by up to one tile)
     const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((budget + budget / 16) / P, 0x7ffffff0ull / P));
     const uint32_t npasses = (spp + smax - 1) / smax;
-    S = (spp + npasses - 1) / npasses;
-  }
+    return (spp + npasses - 1) / npasses;
+  };
+  uint32_t S = std::min(pick_samples(), spp);
+  // The budget is a cached reading of the device's free memory (hipMemGetInfo costs ~0.1 ms).  It is only trusted while the queues this
+  // object already holds are large enough: a batch that has to GROW them asks the device again — another device object, torch films or
+  // RCCL buffers may have taken memory since the reading was made.
+  if ((size_t)P * S > hit.n && !opt.samples_in_flight) { budget_bytes = 0; S = std::min(pick_samples(), spp); }
   S = std::min(S, spp);
   if ((size_t)P * S >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");
 
@@ -800,10 +867,10 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     (void)hipGetLastError();
     for (int q = 0; q < 2; ++q) { ro[q].release(); rd[q].release(); }
     hit.release(); so.release(); sd.release(); sc.release(); pb.release(); pr.release(); pn.release();
-    S = (S + 1) / 2;
+    budget_bytes = 0;  // the reading was stale: the next path_budget() — of this batch, of the next one, of the next frame — asks the device again
+    S = std::min((S + 1) / 2, std::min(pick_samples(), spp));
   }
   paths_in_flight = npaths;
-  HIPCHK(hipMemsetAsync(acc.p, 0, (size_t)P * xs * sizeof(float), stream));
 
   PassBuffers B{};
   for (int q = 0; q < 2; ++q) { B.ro[q] = ro[q].p; B.rd[q] = rd[q].p; }
@@ -813,45 +880,53 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   B.num_pixels = P; B.xstride = xs; B.normals_offset = frame.normals_channel ? frame.primary_components : 0;
   B.seed = frame.sampler_seed;
 
-  const float inv = 1.0f / (float)(spp * opt.paths_per_sample);  // cpu.cpp:191
-  // One event BETWEEN two launches serves as the end of the first and the start of the second (an event record is a packet of its own in
-  // the queue: 42 of them per pass made the gaps between the 21 launches longer than the launches need).  A launch's time then includes
-  // the few microseconds since the previous kernel ended.
-  long last_end = -1;  // index of the event recorded behind the previous timed launch of this batch
-  auto timed_launch = [&](int kind, auto&& fn) -> int {
-    hipEvent_t e; int r;
-    if (last_end < 0) { if ((r = next_event(&e))) return r; HIPCHK(hipEventRecord(e, stream)); last_end = (long)events_used - 1; }
-    const size_t begin = (size_t)last_end;
-    fn();
-    if ((r = next_event(&e))) return r;
-    HIPCHK(hipEventRecord(e, stream));
-    last_end = (long)events_used - 1;
-    timed.push_back({begin, (size_t)last_end, kind});
-    return PHX_OK;
-  };
-  for (uint32_t s0 = 0; s0 < spp; s0 += S) {
-    const uint32_t ns = std::min(S, spp - s0);
-    const uint32_t cap = P * ns;
-    B.num_samples = ns;
-    if ((rc = timed_launch(2, [&]() { launch_begin_pass(stream, B, ns); }))) return rc;
-    int q = 0;
-    for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
-      // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
-      const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
-      if (bounce == 0) {  // the camera rays: one packet walk per 64 x n of them
-        if ((rc = timed_launch(4, [&]() { launch_trace_primary(stream, scene, B, cap, s0, q, sq_read); }))) return rc;
-      } else if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, 1, cap); }))) return rc;
-      if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
-      q ^= 1;
+  // PHX_GRAPH=0: every launch goes straight into the stream (round 4's path; also what a failed capture falls back to)
+  static const bool want_graphs = [] { const char* v = std::getenv("PHX_GRAPH"); return v ? std::atoi(v) != 0 : true; }();
+  BatchGraph* G = &direct;
+  if (want_graphs && !graphs_broken) {
+    // everything the launches of this batch derive their kernels, grids and arguments from
+    struct { DevScene sc; PassBuffers B; uint32_t P, spp, S, depth, pps, xs; float* device_film; } keyed;
+    std::memset(&keyed, 0, sizeof(keyed));
+    keyed.sc = scene; keyed.B = B; keyed.P = P; keyed.spp = spp; keyed.S = S; keyed.depth = opt.path_depth; keyed.pps = opt.paths_per_sample; keyed.xs = xs;
+    keyed.device_film = frame.device_film;
+    uint64_t key = 1469598103934665603ull;  // FNV-1a
+    for (size_t i = 0; i < sizeof(keyed); ++i) { key ^= reinterpret_cast<const unsigned char*>(&keyed)[i]; key *= 1099511628211ull; }
+    BatchGraph* hit_g = nullptr;
+    for (auto* g : graphs) if (g->key == key) hit_g = g;
+    if (!hit_g) {
+      BatchGraph* g = new BatchGraph();
+      g->key = key;
+      hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+      int erc = PHX_OK;
+      if (e == hipSuccess) {
+        erc = enqueue_batch(*g, B, P, S, xs);
+        e = hipStreamEndCapture(stream, &g->graph);  // always: the stream must leave capture mode
+        if (e == hipSuccess && erc == PHX_OK) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+      }
+      if (e != hipSuccess || erc != PHX_OK || !g->exec) {
+        // the direct path has rendered every frame before round 5: fall back to it for the rest of this device's life, and say so
+        std::fprintf(stderr, "libphx_hip: hipGraph capture of a batch failed (%s): launching directly from now on\n", e != hipSuccess ? hipGetErrorString(e) : g_error.c_str());
+        (void)hipGetLastError();
+        drop_graph(*g); delete g;
+        graphs_broken = true;
+      } else {
+        if (graphs.size() >= MAX_GRAPHS) {
+          size_t old = 0;
+          for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i]->last_use < graphs[old]->last_use) old = i;
+          drop_graph(*graphs[old]); delete graphs[old];
+          graphs.erase(graphs.begin() + (long)old);
+        }
+        graphs.push_back(g);
+        hit_g = g;
+      }
     }
-    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;
-    if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
-    HIPCHK(hipGetLastError());
+    if (hit_g) { G = hit_g; G->last_use = ++graph_clock; }
   }
-  // film_t<>::add_tile (film.hpp:12-15)
-  if (frame.device_film) {
-    launch_scatter_film(stream, B, frame.device_film, scene.width);
-    HIPCHK(hipGetLastError());
+  if (G == &direct) {
+    direct.events_used = 0; direct.timed.clear();
+    if ((rc = enqueue_batch(direct, B, P, S, xs))) return rc;
+  } else {
+    HIPCHK(hipGraphLaunch(G->exec, stream));
   }
   if (frame.add_tile || frame.host_film) {
     const size_t nfl = (size_t)P * xs;
@@ -887,6 +962,64 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     }
   } else {
     HIPCHK(hipStreamSynchronize(stream));
+  }
+  // the batch is complete: its launches' HIP-event times (the events belong to the batch's graph, the next launch of it records them again)
+  for (auto& te : G->timed) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, G->events[te.begin], G->events[te.end]));
+    if (te.kind == 0) { stats.closest_ms += ms; stats.trace_launches++; }  // k_trace: closest + shadow rays in one launch
+    else if (te.kind == 4) { stats.primary_ms += ms; stats.primary_launches++; }  // k_trace_primary: the camera rays of a pass
+    else stats.shade_ms += ms;
+    if (te.kind == 3) { stats.shade_kernel_ms += ms; stats.shade_launches++; }
+  }
+  return PHX_OK;
+}
+
+// The launches of one batch, in stream order, into `stream` — which is either live (BatchGraph `direct`) or being captured into a graph.
+int phx_device::enqueue_batch(BatchGraph& g, const PassBuffers& B0, uint32_t P, uint32_t S, uint32_t xs) {
+  int rc;
+  PassBuffers B = B0;
+  const uint32_t spp = opt.samples_per_pixel;
+  HIPCHK(hipMemsetAsync(acc.p, 0, (size_t)P * xs * sizeof(float), stream));
+  const float inv = 1.0f / (float)(spp * opt.paths_per_sample);  // cpu.cpp:191
+  // One event BETWEEN two launches serves as the end of the first and the start of the second (an event record is a packet of its own in
+  // the queue: 42 of them per pass made the gaps between the 21 launches longer than the launches need).  A launch's time then includes
+  // the few microseconds since the previous kernel ended.
+  long last_end = -1;  // index of the event recorded behind the previous timed launch of this batch
+  auto timed_launch = [&](int kind, auto&& fn) -> int {
+    hipEvent_t e; int r;
+    if (last_end < 0) { if ((r = next_event(g, &e))) return r; HIPCHK(hipEventRecord(e, stream)); last_end = (long)g.events_used - 1; }
+    const size_t begin = (size_t)last_end;
+    fn();
+    if ((r = next_event(g, &e))) return r;
+    HIPCHK(hipEventRecord(e, stream));
+    last_end = (long)g.events_used - 1;
+    g.timed.push_back({begin, (size_t)last_end, kind});
+    return PHX_OK;
+  };
+  for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+    const uint32_t ns = std::min(S, spp - s0);
+    const uint32_t cap = P * ns;
+    B.num_samples = ns;
+    if ((rc = timed_launch(2, [&]() { launch_begin_pass(stream, B, ns); }))) return rc;
+    int q = 0;
+    for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
+      // step `bounce`: closest-hit rays of this step + the shadow rays k_shade produced in the previous step
+      const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
+      if (bounce == 0) {  // the camera rays: one packet walk per 64 x n of them
+        if ((rc = timed_launch(4, [&]() { launch_trace_primary(stream, scene, B, cap, s0, q, sq_read); }))) return rc;
+      } else if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, 1, cap); }))) return rc;
+      if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
+      q ^= 1;
+    }
+    if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;
+    if ((rc = timed_launch(2, [&]() { launch_film(stream, B, ns, inv); }))) return rc;
+    HIPCHK(hipGetLastError());
+  }
+  // film_t<>::add_tile (film.hpp:12-15)
+  if (frame.device_film) {
+    launch_scatter_film(stream, B, frame.device_film, scene.width);
+    HIPCHK(hipGetLastError());
   }
   return PHX_OK;
 }

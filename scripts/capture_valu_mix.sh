@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON the GPU box: the VALU peak behind bench.py's roofline, from TODAY's bvh8.h.
+#   1. scripts/micro/valu_mix            -> node tests / triangle tests per second (+ the hash of the sources it was built from)
+#   2. rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE on the same binary -> the shader clock during the node-test kernel
+#      (GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles / 8 / kernel time)
+#   3. scripts/micro/valu_ops            -> issue cost per instruction
+# scripts/valu_mix_json.py merges 1 + 2 into gpurun_out/valu_mix.json (committed as profiles/rNN_valu_mix.json).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+make -C $R/scripts/micro valu_mix valu_ops valu_ops2 > /dev/null 2>&1 || { echo "micro build failed"; exit 1; }
+OUT=$R/gpurun_out/valu_mix
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 120 $R/scripts/micro/valu_mix > $OUT/valu_mix.out 2> $OUT/valu_mix.err || { echo "valu_mix failed"; cat $OUT/valu_mix.err; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -- $R/scripts/micro/valu_mix > $OUT/grbm.log 2>&1; echo "grbm rc=$?"
+timeout -k 10 200 $R/scripts/micro/valu_ops > $OUT/valu_ops.json 2> $OUT/valu_ops.err; echo "valu_ops rc=$?"
+timeout -k 10 200 $R/scripts/micro/valu_ops2 > $OUT/valu_ops2.json 2> $OUT/valu_ops2.err; echo "valu_ops2 rc=$?"
+python3 $R/scripts/valu_mix_json.py $OUT > $R/gpurun_out/valu_mix.json && cat $R/gpurun_out/valu_mix.json

@@ -4,8 +4,12 @@
 // active, no global memory, 8 waves per SIMD.  The two rates are the VALU ceiling k_trace is priced against: a frame that
 // needs V node visits and T triangle tests cannot finish faster than V / node_rate + T / tri_rate, however the rays are
 // fed.  (k_trace is VALU-issue bound: profiles/README.md.)
-// Build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I phosphorus_mk2_amd/csrc -o valu_mix scripts/micro/valu_mix.hip
-// Run:   ./valu_mix   -> one JSON line
+// The JSON line carries the hash of the bvh8.h functions this binary was built from (scripts/src_hash.py, -DPHX_SRC_HASH by the Makefile:
+// bench.py refuses a peak from other sources) and the shader clock DURING the node-test kernel: s_memtime ticks over the kernel against the
+// constant-rate wall clock — meaningful only if s_memtime follows the shader clock on this part, so the capture script also takes
+// GRBM_GUI_ACTIVE / 8 / kernel time with rocprofv3 (scripts/capture_valu_mix.sh) and that figure is the one recorded as clock_hz.
+// Build: make -C scripts/micro valu_mix
+// Run:   scripts/micro/valu_mix   -> one JSON line
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -18,8 +22,13 @@ using namespace phx;
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
 // MODE 0: node tests, MODE 1: triangle tests, MODE 2: the loop skeleton alone (what the perturbation of the operands costs)
+#ifndef PHX_SRC_HASH
+#define PHX_SRC_HASH "unknown"
+#endif
+
 template <int MODE>
-__global__ void __launch_bounds__(256, 8) k(SceneGrid grid, int iters, uint32_t* out) {
+__global__ void __launch_bounds__(256, 8) k(SceneGrid grid, int iters, uint32_t* out, unsigned long long* ticks) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
   __shared__ uint8_t lut[2048];
   for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
   __syncthreads();
@@ -50,18 +59,19 @@ __global__ void __launch_bounds__(256, 8) k(SceneGrid grid, int iters, uint32_t*
     }
   }
   out[tid] = acc + __float_as_uint(tbest);
+  if (tid == 0) { ticks[0] = clock64() - c0; ticks[1] = wall_clock64() - w0; }
 }
 
 template <int MODE>
-static double run(int grid_blocks, int iters, uint32_t* d_out) {
+static double run(int grid_blocks, int iters, uint32_t* d_out, unsigned long long* d_ticks) {
   SceneGrid g; for (int a = 0; a < 3; ++a) { g.lo[a] = -1.0f; g.cell[a] = 7.6e-6f; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<MODE>, dim3(grid_blocks), dim3(256), 0, 0, g, iters / 8, d_out);  // warm-up
+  hipLaunchKernelGGL(k<MODE>, dim3(grid_blocks), dim3(256), 0, 0, g, iters / 8, d_out, d_ticks);  // warm-up
   hipDeviceSynchronize();
   double best = 1e30;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k<MODE>, dim3(grid_blocks), dim3(256), 0, 0, g, iters, d_out);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid_blocks), dim3(256), 0, 0, g, iters, d_out, d_ticks);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
@@ -73,13 +83,17 @@ int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount, blocks = cus * 8, iters = 20000;  // 8 blocks x 4 waves = 32 waves per CU = 8 per SIMD
   uint32_t* d_out; hipMalloc((void**)&d_out, (size_t)blocks * 256 * 4);
-  const double t_skel = run<2>(blocks, iters, d_out), t_node = run<0>(blocks, iters, d_out), t_tri = run<1>(blocks, iters, d_out);
+  unsigned long long* d_ticks; hipMalloc((void**)&d_ticks, 16);
+  int wall_khz = 0; hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+  const double t_skel = run<2>(blocks, iters, d_out, d_ticks), t_tri = run<1>(blocks, iters, d_out, d_ticks), t_node = run<0>(blocks, iters, d_out, d_ticks);
+  unsigned long long h_ticks[2] = {0, 0}; hipMemcpy(h_ticks, d_ticks, 16, hipMemcpyDeviceToHost);  // of the last node-test launch
+  const double memtime_hz = h_ticks[1] ? (double)h_ticks[0] / (double)h_ticks[1] * wall_khz * 1e3 : 0.0;
   const double lanes = (double)blocks * 256.0;
   // the skeleton (operand perturbation + loop) is subtracted: it is not part of the test being priced
   const double node_rate = lanes * iters / (t_node - t_skel), tri_rate = lanes * iters / (t_tri - t_skel);
-  std::printf("{\"device\": \"%s\", \"cus\": %d, \"waves_per_simd\": 8, \"iters\": %d, \"t_skeleton_s\": %.6f, \"t_node_s\": %.6f, \"t_tri_s\": %.6f, "
+  std::printf("{\"device\": \"%s\", \"src_hash\": \"%s\", \"s_memtime_hz_during_node_kernel\": %.4e, \"wall_clock_khz\": %d, \"cus\": %d, \"waves_per_simd\": 8, \"iters\": %d, \"t_skeleton_s\": %.6f, \"t_node_s\": %.6f, \"t_tri_s\": %.6f, "
               "\"node_tests_per_s\": %.6e, \"tri_tests_per_s\": %.6e, \"ns_per_node_test_per_cu\": %.4f, \"ns_per_tri_test_per_cu\": %.4f}\n",
-              p.gcnArchName, cus, iters, t_skel, t_node, t_tri, node_rate, tri_rate, 1e9 * cus / node_rate, 1e9 * cus / tri_rate);
-  hipFree(d_out);
+              p.gcnArchName, PHX_SRC_HASH, memtime_hz, wall_khz, cus, iters, t_skel, t_node, t_tri, node_rate, tri_rate, 1e9 * cus / node_rate, 1e9 * cus / tri_rate);
+  hipFree(d_out); hipFree(d_ticks);
   return 0;
 }

@@ -30,8 +30,41 @@ def test_committed_measurements_come_from_the_newest_profile_of_this_workload():
     assert cap and src.startswith("profiles/r") and os.path.exists(os.path.join(ROOT, src))
     assert cap["kernels"]["k_trace"]["hbm_bytes_per_launch_corrected"] > 1e9
     assert bench.workload_tag("soup", 12345, 1280, 720, 9) is None and bench.load_capture(None) == (None, None)  # another workload: no PMC figure is claimed
-    peak, psrc = bench.committed_valu_peak()
+    peak, psrc, refused = bench.committed_valu_peak()
+    assert refused is None, refused  # the newest committed peak was measured on the node / triangle test of THIS tree
     assert peak["node_tests_per_s"] > 1e10 and peak["tri_tests_per_s"] > peak["node_tests_per_s"] and os.path.exists(os.path.join(ROOT, psrc))
+    assert peak["src_hash"] == bench.priced_source_hash() and 1.5e9 < peak["clock_hz"] < 2.6e9
+
+
+def test_a_peak_measured_on_other_sources_is_refused(monkeypatch):
+    """the VALU peak behind roofline.frac carries the hash of the bvh8.h functions it timed (scripts/src_hash.py); when the tree's
+    node test or triangle test has changed since, bench.py reports frac = None with the reason instead of a fraction of a stale peak"""
+    import bench
+    from scripts import src_hash
+    h = src_hash.priced_source_hash()
+    assert len(h) == 16 and h == bench.priced_source_hash()
+    # the hash follows the text of the priced functions and nothing else
+    src = open(src_hash.BVH8).read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for edit, same in ((src.replace("struct Hit {", "struct Hit  {"), True),
+                           (src.replace("const float pad_far = 1.00000095367431640625f;", "const float pad_far = 1.0000019073486328125f;"), False),
+                           (src.replace("const bool umask = us >= 0.0f;", "const bool umask = us > 0.0f;"), False)):
+            assert edit != src
+            f = os.path.join(d, "bvh8.h"); open(f, "w").write(edit)
+            assert (src_hash.priced_source_hash(f) == h) == same
+    work = {k: {"rays": r, "node_visits_lds_per_ray": 5.3, "node_visits_mem_per_ray": 9.0, "tri_tests_per_ray": 5.5} for k, r in (("closest", 441_000_000), ("shadow", 123_000_000))}
+    work["wave"] = {"lanes_per_node_block": 52.0, "lanes_per_tri_block": 22.0}
+    acc = bench.new_acc()
+    acc.update({"closest": 441_000_000, "shadow": 123_000_000, "camera": 235_929_600, "closest_ms": 73.0, "shade_ms": 16.0, "launches": 10, "frame_ms": 90.0})
+    ok = bench.roofline(acc, 1, work, "100k", None)
+    assert ok["frac"] is not None and "frac_unavailable" not in ok and ok["work"]["peak_src_hash"] == h
+    monkeypatch.setattr(bench, "priced_source_hash", lambda: "0123456789abcdef")
+    stale = bench.roofline(acc, 1, work, "100k", None)
+    assert stale["frac"] is None and stale["achieved"] is None and "stale peak" in stale["frac_unavailable"] and "0123456789abcdef" in stale["frac_unavailable"]
+    assert stale["stream_GBps"] == ok["stream_GBps"] and stale["diagnostics"] == ok["diagnostics"]  # everything measured stays
+    line = bench.compact_roofline(stale)
+    assert line["frac"] is None and "stale peak" in line["frac_unavailable"]
 
 
 def test_roofline_fraction_is_work_based_and_diagnostics_use_their_own_capture():

@@ -130,3 +130,50 @@ def test_bmw_standin_configs_at_film_size(orc, width, height):
         a, b = film[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3]
         fin = np.isfinite(b).all(-1)
         assert np.array_equal(fin, np.isfinite(a).all(-1)) and fin.mean() > 0.99 and bits_equal(a[fin], b[fin]), (x, y)
+
+
+@pytest.mark.parametrize("width,height,spp", [(1920, 1080, 1024), (3840, 2160, 4096)])
+def test_bmw_standin_configs_at_their_real_sample_counts(orc, width, height, spp):
+    """BASELINE configs #3 and #5 at the sample counts BASELINE names — 1 024 and 4 096 spp: 32x32 / 64x64 jitter strata
+    (src/sampling.cpp:98-112), path id = pixel * spp + sample, every sample of a pixel in ONE pass (src/xpu/cpu.cpp:160-198 runs
+    them as a loop per tile) — on two 32x32 tiles of the stand-in scene, one of them in the film's edge band (1080 = 33 * 32 + 24,
+    2160 = 67 * 32 + 16): device against oracle under BOTH tie rules.  Under the device's rule ray counts and film are exact; under
+    the reference's first-met rule the film stays inside the north-star gate and the ray counts within a few rays."""
+    from phosphorus_mk2_amd import scenes, xpu
+    xpu.load_library()
+    sc = scenes.multi_material_soup(500_000, width=width, height=height)
+    ty = (height // 32) * 32
+    tiles = [(32 * (width // 64), 32 * (height // 64), 32, 32), (32 * 9, ty, 32, height - ty)]
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=9))
+    try:
+        dev.preprocess(sc)
+        film = xpu.Film(width, height, 4)
+        dev.start(sc, xpu.FrameState(23, xpu.CallbackTiles(tiles), film))
+        dev.join()
+        st = dev.stats()
+    finally:
+        dev.close()
+    npix = sum(w * h for (_, _, w, h) in tiles)
+    assert st["camera_samples"] == npix * spp and st["tiles"] == 2
+    assert st["paths_in_flight"] == npix * spp  # one pass carries every sample of the batch's pixels
+    O = orc.Oracle(sc, spp=spp, pps=1, depth=9)
+    try:
+        orc.set_tie_rule(1)
+        try:
+            ref, ost = O.render(rng=orc.RNG_COUNTER, seed=23, threads=2, tiles=tiles)
+        finally:
+            orc.set_tie_rule(0)
+        ref0, ost0 = O.render(rng=orc.RNG_COUNTER, seed=23, threads=2, tiles=tiles)
+    finally:
+        O.close()
+    for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+        assert abs(st[k] - ost0[k]) <= 8, (k, st[k], ost0[k])
+    for (x, y, w, h) in tiles:
+        a, b, b0 = film.data[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3], ref0[y:y + h, x:x + w, :3]
+        fin = np.isfinite(b).all(-1)
+        assert np.array_equal(fin, np.isfinite(a).all(-1)) and fin.mean() > 0.99 and bits_equal(a[fin], b[fin]), (x, y)
+        fin0 = fin & np.isfinite(b0).all(-1)
+        d = a[fin0].astype(np.float64) - b0[fin0].astype(np.float64)
+        assert float(np.sqrt((d * d).sum(-1)).max(initial=0.0)) < 1e-4, (x, y)  # the north star's gate, reference tie rule
+    assert float(np.nanmax(film.data[..., :3])) > 0.0 and ost["rays_shadow"] > 0

@@ -786,6 +786,34 @@ def test_full_size_properties(xpu, orc):
         assert abs(st[k] - ost0[k]) <= 4, (k, st[k], ost0[k])
 
 
+def test_tie_rule_deviation_on_the_1M_soup_is_one_pixel(xpu, orc):
+    """The documented deviation, kept measurable: the device gives equal-distance hits to the lowest primitive index, the reference to
+    whichever triangle ITS traversal of ITS tree meets first (src/accel/triangle.hpp:166-179).  On Soup(1 M) at 64 spp that costs
+    exactly ONE pixel of 921 600 the north-star gate (L2 0.131: one camera ray whose tie goes the other way — a different material
+    behind it); under the device's rule the whole film is exact.  The COUNT is pinned so that a regression to many is caught."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(1_000_000, seed=1234, width=1280, height=720)
+    film, st = xpu.render(sc, spp=64, seed=1, native_sink=True)
+    O = orc.Oracle(sc, spp=64, pps=1, depth=9)
+    try:
+        orc.set_tie_rule(1)
+        try:
+            ref, ost = O.render(rng=orc.RNG_COUNTER, seed=1, threads=16)
+        finally:
+            orc.set_tie_rule(0)
+        ref0, ost0 = O.render(rng=orc.RNG_COUNTER, seed=1, threads=16)
+    finally:
+        O.close()
+    for k in ("rays_closest", "rays_shadow", "rays_masked"):
+        assert st[k] == ost[k], k
+        assert abs(st[k] - ost0[k]) <= 4, (k, st[k], ost0[k])
+    assert bits_equal(film[..., :3], ref[..., :3])
+    d0 = film[..., :3].astype(np.float64) - ref0[..., :3].astype(np.float64)
+    l2 = np.sqrt((d0 * d0).sum(-1))
+    assert int((l2 > L2_TOL).sum()) == 1 and 0.05 < float(l2.max()) < 0.3, (int((l2 > L2_TOL).sum()), float(l2.max()))
+    assert int((l2 > 0).sum()) <= 4
+
+
 def test_baseline_config_1_at_its_real_size(xpu, orc):
     """BASELINE.json configs[0]: the Cornell box (12 triangles, 1 area light), 256x256, 64 spp, depth 9 — the reference's own
     CPU-runnable case, whole frame, device against oracle: ray counts exact and the film bit for bit under the device's tie rule;
@@ -809,24 +837,44 @@ def test_baseline_config_1_at_its_real_size(xpu, orc):
     assert int((l2 > L2_TOL).sum()) == 0 and int((l2 > 0).sum()) <= 2
 
 
-def test_auto_builder_falls_back_to_the_host_when_the_device_build_fails(xpu, orc):
-    """PHX_BVH_AUTO builds on the device; if that build fails (no scratch memory, a tree deeper than its tables) preprocess must
-    not: the host's binned-SAH builder takes over, phx_stats says so, and the film is the same.  An explicit DEVICE_LBVH request
-    still fails loudly.  PHX_TEST_FAIL_DEVICE_BUILD is the test hook that makes build_bvh8_gpu report failure."""
-    import os
+def test_auto_builder_falls_back_to_the_host_only_for_recoverable_failures(xpu, orc):
+    """PHX_BVH_AUTO builds on the device; if that build cannot get its memory or meets a tree deeper than its tables (a RECOVERABLE
+    failure) preprocess must not fail: the host's binned-SAH builder takes over, says so on stderr and in phx_stats, and the film is the
+    same.  Any other failure of the device builder (a HIP error, lost triangles) fails preprocess even under AUTO, and an explicit
+    DEVICE_LBVH request always fails loudly.  The fault injection lives in a twin library (libphx_hip_hooks.so, -DPHX_TEST_HOOKS=1):
+    the product library does not read PHX_TEST_FAIL_DEVICE_BUILD."""
+    import os, subprocess, sys, hashlib
+    from conftest import ROOT
     from phosphorus_mk2_amd import scenes
     sc = scenes.soup(5000, width=64, height=64)
-    want, wst = xpu.render(sc, spp=4, seed=2)
-    assert wst["bvh_built_on_device"] == 1
-    os.environ["PHX_TEST_FAIL_DEVICE_BUILD"] = "1"
+    os.environ["PHX_TEST_FAIL_DEVICE_BUILD"] = "recoverable"
     try:
-        got, gst = xpu.render(sc, spp=4, seed=2)
-        with pytest.raises(xpu.DeviceError, match="device BVH build"):
-            xpu.render(sc, spp=4, seed=2, bvh_builder="device")
+        want, wst = xpu.render(sc, spp=4, seed=2)  # the product library ignores the variable
     finally:
         del os.environ["PHX_TEST_FAIL_DEVICE_BUILD"]
-    assert gst["bvh_built_on_device"] == 0 and bits_equal(got, want) and gst["rays_closest"] == wst["rays_closest"]
-    again, ast_ = xpu.render(sc, spp=4, seed=2)  # the failure left no sticky HIP error behind
+    assert wst["bvh_built_on_device"] == 1
+    hooks = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_hooks.so")
+    assert os.path.exists(hooks), "build() makes the fault-injection twin"
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from phosphorus_mk2_amd import scenes, xpu\n"
+            "sc = scenes.soup(5000, width=64, height=64)\n"
+            "for builder in ('auto', 'device'):\n"
+            "    try:\n"
+            "        film, st = xpu.render(sc, spp=4, seed=2, bvh_builder=builder)\n"
+            "        print(builder, 'RENDERED', st['bvh_built_on_device'], st['rays_closest'], hashlib.sha1(film.tobytes()).hexdigest())\n"
+            "    except xpu.DeviceError as e:\n"
+            "        print(builder, 'FAILED:', e)\n") % ROOT
+    out = {}
+    for how in ("recoverable", "fatal"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=dict(os.environ, PHX_LIB=hooks, PHX_TEST_FAIL_DEVICE_BUILD=how))
+        assert r.returncode == 0, (r.stdout, r.stderr[-800:])
+        out[how] = ({l.split()[0]: l for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("auto", "device")}, r.stderr)
+    rec, rec_err = out["recoverable"]
+    assert rec["auto"].split()[1:4] == ["RENDERED", "0", str(wst["rays_closest"])] and rec["auto"].split()[4] == hashlib.sha1(want.tobytes()).hexdigest()
+    assert "fell back to the host builder" in rec_err and "FAILED:" in rec["device"] and "device BVH build" in rec["device"]
+    fat, fat_err = out["fatal"]
+    assert "FAILED:" in fat["auto"] and "device BVH build" in fat["auto"] and "FAILED:" in fat["device"] and "fell back" not in fat_err
+    again, ast_ = xpu.render(sc, spp=4, seed=2)
     assert ast_["bvh_built_on_device"] == 1 and bits_equal(again, want)
 
 
