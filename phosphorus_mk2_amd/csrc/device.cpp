@@ -120,28 +120,19 @@ struct phx_device {
   uint64_t paths_in_flight = 0;
   double bvh_cost_model = 0; uint32_t bvh_built_on_device = 0;
   struct Timed { size_t begin, end; int kind; };  // (event before, event behind, kind 0 k_trace / 2 begin-pass, film / 3 shade / 4 k_trace_primary)
-  // The launches of a batch — memset, [begin-pass, camera rays, shade, (trace, shade) x (depth - 1), trace, film] per pass, film scatter:
-  // 21 kernels per pass at depth 9, one event between consecutive ones — as ONE hipGraph, captured the first time a batch with these
-  // kernel arguments is met and launched with a single call afterwards (a frame loop presents the same batches again and again).
-  // A graph encodes nothing but (kernel, grid, block, LDS bytes, arguments), so the cache key is a hash of everything those derive from.
-  struct BatchGraph {
-    uint64_t key = 0, last_use = 0;
-    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  // The launches of a batch and the HIP events between them.  (Round 5 captured a batch's launches — memset, [begin-pass, camera rays,
+  // shade, (trace, shade) x (depth - 1), trace, film] per pass, film scatter — as ONE hipGraph, cached by a hash of the kernel arguments:
+  // rank 0 of 8 of the bench frame 9.12-9.27 ms with direct launches and events, 9.08-9.37 without events, 9.14-9.16 as a graph — nothing,
+  // the fixed costs of a short frame are k_trace's drain tails on the GPU, not the host's enqueue; and an event recorded by a graph's
+  // event-record node cannot be read with hipEventElapsedTime on ROCm 7.2.  profiles/r05_b_graph_rank_share.log, r05_b_graph.patch.)
+  struct BatchLaunches {
     std::vector<hipEvent_t> events; size_t events_used = 0;
     std::vector<Timed> timed;
   };
-  std::vector<BatchGraph*> graphs;  // at most MAX_GRAPHS, least recently used goes first
-  BatchGraph direct;                // the same launches straight into the stream (PHX_GRAPH=0, or after a capture failed)
-  uint64_t graph_clock = 0; bool graphs_broken = false;
-  enum { MAX_GRAPHS = 16 };
+  BatchLaunches direct;
+  bool kernel_timing = true;        // per-kernel HIP events (phx_stats::closest_ms ...); PHX_KERNEL_TIMING=0 launches without them (probe)
   std::chrono::steady_clock::time_point t_start, t_enq, t_sync;  // host timing probe (PHX_HOST_TIMING)
 
-  static void drop_graph(BatchGraph& g) {
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (g.graph) (void)hipGraphDestroy(g.graph);
-    for (auto e : g.events) (void)hipEventDestroy(e);
-    g.exec = nullptr; g.graph = nullptr; g.events.clear(); g.events_used = 0; g.timed.clear();
-  }
   ~phx_device() {
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -149,13 +140,12 @@ struct phx_device {
     }
     cv.notify_all();
     if (driver.joinable()) driver.join();
-    for (auto* g : graphs) { drop_graph(*g); delete g; }
-    drop_graph(direct);
+    for (auto e : direct.events) (void)hipEventDestroy(e);
     if (h_acc) (void)hipHostFree(h_acc);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
-  static int next_event(BatchGraph& g, hipEvent_t* out) {
+  static int next_event(BatchLaunches& g, hipEvent_t* out) {
     if (g.events_used == g.events.size()) {
       hipEvent_t e; HIPCHK(hipEventCreate(&e));
       g.events.push_back(e);
@@ -190,7 +180,7 @@ struct phx_device {
   }
   void driver_loop();
   int run_frame();
-  int enqueue_batch(BatchGraph& g, const PassBuffers& B0, uint32_t P, uint32_t S, uint32_t xs);
+  int enqueue_batch(BatchLaunches& g, const PassBuffers& B0, uint32_t P, uint32_t S, uint32_t xs);
   int render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit);
 };
 
@@ -524,6 +514,10 @@ int phx_dev_start(phx_device* d, const phx_frame* f) {
   if (!f->add_tile && !f->device_film && !f->host_film) return fail(PHX_ERR_ARG, "frame without a film sink");
   if (f->primary_components != 3 && f->primary_components != 4) return fail(PHX_ERR_ARG, "primary channel must have 3 or 4 components");
   d->frame = *f;
+  {
+    static const int timing_env = [] { const char* v = std::getenv("PHX_KERNEL_TIMING"); return v ? std::atoi(v) : -1; }();
+    d->kernel_timing = timing_env >= 0 ? timing_env != 0 : true;
+  }
   d->t_start = std::chrono::steady_clock::now();
   const int rc = guarded([&]() {
     if (!d->driver.joinable()) d->driver = std::thread([d]() { d->driver_loop(); });  // the first frame of this device starts its driver
@@ -880,54 +874,9 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   B.num_pixels = P; B.xstride = xs; B.normals_offset = frame.normals_channel ? frame.primary_components : 0;
   B.seed = frame.sampler_seed;
 
-  // PHX_GRAPH=0: every launch goes straight into the stream (round 4's path; also what a failed capture falls back to)
-  static const bool want_graphs = [] { const char* v = std::getenv("PHX_GRAPH"); return v ? std::atoi(v) != 0 : true; }();
-  BatchGraph* G = &direct;
-  if (want_graphs && !graphs_broken) {
-    // everything the launches of this batch derive their kernels, grids and arguments from
-    struct { DevScene sc; PassBuffers B; uint32_t P, spp, S, depth, pps, xs; float* device_film; } keyed;
-    std::memset(&keyed, 0, sizeof(keyed));
-    keyed.sc = scene; keyed.B = B; keyed.P = P; keyed.spp = spp; keyed.S = S; keyed.depth = opt.path_depth; keyed.pps = opt.paths_per_sample; keyed.xs = xs;
-    keyed.device_film = frame.device_film;
-    uint64_t key = 1469598103934665603ull;  // FNV-1a
-    for (size_t i = 0; i < sizeof(keyed); ++i) { key ^= reinterpret_cast<const unsigned char*>(&keyed)[i]; key *= 1099511628211ull; }
-    BatchGraph* hit_g = nullptr;
-    for (auto* g : graphs) if (g->key == key) hit_g = g;
-    if (!hit_g) {
-      BatchGraph* g = new BatchGraph();
-      g->key = key;
-      hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
-      int erc = PHX_OK;
-      if (e == hipSuccess) {
-        erc = enqueue_batch(*g, B, P, S, xs);
-        e = hipStreamEndCapture(stream, &g->graph);  // always: the stream must leave capture mode
-        if (e == hipSuccess && erc == PHX_OK) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-      }
-      if (e != hipSuccess || erc != PHX_OK || !g->exec) {
-        // the direct path has rendered every frame before round 5: fall back to it for the rest of this device's life, and say so
-        std::fprintf(stderr, "libphx_hip: hipGraph capture of a batch failed (%s): launching directly from now on\n", e != hipSuccess ? hipGetErrorString(e) : g_error.c_str());
-        (void)hipGetLastError();
-        drop_graph(*g); delete g;
-        graphs_broken = true;
-      } else {
-        if (graphs.size() >= MAX_GRAPHS) {
-          size_t old = 0;
-          for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i]->last_use < graphs[old]->last_use) old = i;
-          drop_graph(*graphs[old]); delete graphs[old];
-          graphs.erase(graphs.begin() + (long)old);
-        }
-        graphs.push_back(g);
-        hit_g = g;
-      }
-    }
-    if (hit_g) { G = hit_g; G->last_use = ++graph_clock; }
-  }
-  if (G == &direct) {
-    direct.events_used = 0; direct.timed.clear();
-    if ((rc = enqueue_batch(direct, B, P, S, xs))) return rc;
-  } else {
-    HIPCHK(hipGraphLaunch(G->exec, stream));
-  }
+  BatchLaunches* G = &direct;
+  direct.events_used = 0; direct.timed.clear();
+  if ((rc = enqueue_batch(direct, B, P, S, xs))) return rc;
   if (frame.add_tile || frame.host_film) {
     const size_t nfl = (size_t)P * xs;
     if (nfl > h_acc_n) {
@@ -963,7 +912,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   } else {
     HIPCHK(hipStreamSynchronize(stream));
   }
-  // the batch is complete: its launches' HIP-event times (the events belong to the batch's graph, the next launch of it records them again)
+  // the batch is complete: its launches' HIP-event times (the next batch records the same events again)
   for (auto& te : G->timed) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, G->events[te.begin], G->events[te.end]));
@@ -975,8 +924,8 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   return PHX_OK;
 }
 
-// The launches of one batch, in stream order, into `stream` — which is either live (BatchGraph `direct`) or being captured into a graph.
-int phx_device::enqueue_batch(BatchGraph& g, const PassBuffers& B0, uint32_t P, uint32_t S, uint32_t xs) {
+// The launches of one batch, in stream order.
+int phx_device::enqueue_batch(BatchLaunches& g, const PassBuffers& B0, uint32_t P, uint32_t S, uint32_t xs) {
   int rc;
   PassBuffers B = B0;
   const uint32_t spp = opt.samples_per_pixel;
@@ -988,6 +937,7 @@ int phx_device::enqueue_batch(BatchGraph& g, const PassBuffers& B0, uint32_t P, 
   long last_end = -1;  // index of the event recorded behind the previous timed launch of this batch
   auto timed_launch = [&](int kind, auto&& fn) -> int {
     hipEvent_t e; int r;
+    if (!kernel_timing) { fn(); return PHX_OK; }
     if (last_end < 0) { if ((r = next_event(g, &e))) return r; HIPCHK(hipEventRecord(e, stream)); last_end = (long)g.events_used - 1; }
     const size_t begin = (size_t)last_end;
     fn();

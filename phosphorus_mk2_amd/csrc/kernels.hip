@@ -924,6 +924,16 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #ifndef PHX_SHADE_TIMING
 #define PHX_SHADE_TIMING 0  /* probe builds only: s_memtime around k_shade_g's sort phase and shading rounds, summed into DevStats fields the count build uses */
 #endif
+// probe builds (-DPHX_SHADE_TIMING=1, scripts/shade_phase_probe.py): s_memtime at the phase boundaries of a shading round, per wave.
+// PHX_PHASE(n) closes phase n: everything the wave has in flight is waited for first, so that a phase is charged the latency of what it
+// asked for (loads issued in a phase and consumed later would otherwise be billed to the consumer).
+#if PHX_SHADE_TIMING
+#define PHX_PHASE_DECL long long ph_t = clock64(); unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PHX_PHASE(n) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long now_ = clock64(); ph_acc[n] += (unsigned long long)(now_ - ph_t); ph_t = now_; }
+#else
+#define PHX_PHASE_DECL
+#define PHX_PHASE(n)
+#endif
 #ifndef PHX_SCALAR_F
 #define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
 #endif
@@ -953,10 +963,12 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   __shared__ uint16_t perm[WINDOW];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   if (blockIdx.x == 0 && threadIdx.x == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
-  for (uint32_t base = blockIdx.x * WINDOW; base < count; base += gridDim.x * WINDOW) {
+  PHX_PHASE_DECL
 #if PHX_SHADE_TIMING
-    const long long tm0 = clock64();
+  unsigned long long ph_rounds = 0, ph_windows = 0;
 #endif
+  for (uint32_t base = blockIdx.x * WINDOW; base < count; base += gridDim.x * WINDOW) {
+    PHX_PHASE(5)  // (the barrier at the end of the previous window, loop overhead)
     // ---- counting sort of the window by material, through LDS
     if (threadIdx.x < NB + 2) bucket[threadIdx.x] = 0;
     __syncthreads();
@@ -989,8 +1001,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) perm[bucket[keys[k]] + ranks[k]] = (uint16_t)(k * BLOCK + threadIdx.x);
     __syncthreads();
+    PHX_PHASE(0)  // the window's sort by material
 #if PHX_SHADE_TIMING
-    const long long tm1 = clock64();
+    ++ph_windows;
 #endif
     // ---- the window in sorted order: wave w of round k shades sorted positions [k * BLOCK + 64 w, + 64)
     for (int k = 0; k < ITEMS; ++k) {
@@ -1057,6 +1070,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
         }
       }
+      PHX_PHASE(1)  // hit record, ray, path state, triangle record, normals: requested and landed; emission added
       // the hit's tangent frame (orthogonal_base_t): once per hit, for the NEE evaluation and the BSDF sample
       const Frame fr(hit_surface ? n : v3(0.0f, 1.0f, 0.0f));
       // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
@@ -1109,6 +1123,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           }
         }
       }
+      PHX_PHASE(2)  // next-event estimation: light sample, bsdf_f, li
       // ---- integrate: ++depth, russian roulette, bsdf sampling (spt.hpp:188-190, 257-328)
       {
         v3 nxt_d; uint32_t next_specular = 0; float off = 0.0f;
@@ -1147,8 +1162,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         // both queues in one go: two barriers and two concurrent atomics per round (appending the NEE ray before roulette and sampling
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
+        PHX_PHASE(3)  // roulette, bsdf_sample, path state store
         uint32_t no, ns;
         block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns);
+        PHX_PHASE(4)  // the append: two barriers and the workgroup's two atomics on the queue counters
         if (want_shadow) {
           pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
           pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
@@ -1159,16 +1176,20 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
           pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
         }
+        PHX_PHASE(5)  // the stores of the two queue entries (waited for: the probe charges them here, the product build does not wait)
+#if PHX_SHADE_TIMING
+        ++ph_rounds;
+#endif
       }
     }
-#if PHX_SHADE_TIMING
-    if ((threadIdx.x & 63u) == 0u) {  // probe build only: cycles of the sort phase / of the shading rounds, per wave
-      const long long tm2 = clock64();
-      atomicAdd(&pb.stats->wave_iters, (unsigned long long)(tm1 - tm0)); atomicAdd(&pb.stats->node_block_execs, (unsigned long long)(tm2 - tm1)); atomicAdd(&pb.stats->refills, 1ull);
-    }
-#endif
     __syncthreads();  // perm and bucket are rewritten by the next window
   }
+#if PHX_SHADE_TIMING
+  if ((threadIdx.x & 63u) == 0u) {  // probe build only: s_memtime ticks per phase, summed over the waves (DevStats fields of the count build)
+    for (int k = 0; k < 6; ++k) atomicAdd(&pb.stats->stack_pushes[k], ph_acc[k]);
+    atomicAdd(&pb.stats->stack_pushes[6], ph_rounds); atomicAdd(&pb.stats->stack_pushes[7], ph_windows);
+  }
+#endif
 }
 
 // ---- film -------------------------------------------------------------------------------------------

@@ -1,10 +1,25 @@
-"""Run ON the GPU box after `make -C phosphorus_mk2_amd/csrc variant NAME=shtime EXTRA=-DPHX_SHADE_TIMING=1`: how k_shade_g's wave cycles split between
-the material sort of a window and its eight shading rounds (s_memtime per wave, summed).  Round 4: sort 16 %, shading rounds 84 %."""
+"""Run ON the GPU box after `make -C phosphorus_mk2_amd/csrc variant NAME=shtime EXTRA=-DPHX_SHADE_TIMING=1`: where k_shade_g's wave time goes.
+s_memtime at the phase boundaries of every shading round, per wave, everything in flight waited for at each boundary (so a phase is charged the
+latency of what it asked for); summed over waves and launches.  Prints a markdown table.  (Round 4's two-phase version: sort 16 %, rounds 84 %.)
+    python scripts/shade_phase_probe.py [width height spp]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 os.environ["PHX_LIB"] = os.path.join(os.getcwd(), "phosphorus_mk2_amd", "libphx_hip_shtime.so")
 from phosphorus_mk2_amd import scenes, xpu
-sc = scenes.multi_material_soup(500000, width=1920, height=1080)
-film, st = xpu.render(sc, spp=256, seed=1, native_sink=True)
-tot = st["wave_iters"] + st["node_block_execs"]
-print("windows x waves", st["refills"], "sort cycles %.3g shade cycles %.3g -> sort share %.3f" % (st["wave_iters"], st["node_block_execs"], st["wave_iters"] / tot), "shade_kernel_ms", st["shade_kernel_ms"])
+W, H, SPP = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (1920, 1080, 256)))
+sc = scenes.multi_material_soup(500000, width=W, height=H)
+film, st = xpu.render(sc, spp=SPP, seed=1, native_sink=True)
+ph = list(st["stack_pushes"])
+names = ["sort of the window by material (hit record + material gather, LDS histogram, scan, scatter of the permutation)",
+         "loads landed: permuted index, hit record, ray, path state, triangle record, normals; emission added",
+         "next-event estimation: light sample, bsdf_f, li",
+         "roulette + bsdf_sample + path-state store",
+         "append: two barriers + the workgroup's two atomics on the queue counters",
+         "stores of the next ray / shadow ray (waited for) + end-of-window barrier"]
+tot = float(sum(ph[:6]))
+print(f"k_shade_g phase probe: multi_material_soup(500 000) {W}x{H} {SPP} spp; shade kernel {st['shade_kernel_ms']:.2f} ms (probe build: every phase boundary waits for everything in flight), "
+      f"{ph[7]} wave-windows, {ph[6]} wave-rounds, {st['rays_closest']} entries shaded\n")
+print("| phase | share of wave time | ticks per wave-round |")
+print("|---|---|---|")
+for n, t in zip(names, ph[:6]):
+    print(f"| {n} | {t / tot:.3f} | {t / max(1, ph[6]):.0f} |")
