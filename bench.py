@@ -37,9 +37,9 @@ secondary records — goes to --full-json (default gpurun_out/bench_full.json). 
                frame (counter RNG) for >= 10 s; thread start-up and per-thread stream construction are outside the clock.
   secondary    the same measurement on Soup(1 M) (the north star's target scene), on the whole BASELINE config-4 frame
                (Soup(10 M), 3840x2160, 256 spp) on this one GPU, and on the declared stand-ins for BASELINE configs 3 and 5 (no BMW
-               scene ships with the reference): the 16-recipe multi_material_soup(500 000) at 1920x1080, 256 of 1024 spp (whole frame)
-               and at 3840x2160 with the full 4096 spp on every 64th tile — those two carry a roofline of the general-closure shade
-               kernel, k_shade_g.
+               scene ships with the reference): the 16-recipe multi_material_soup(500 000) at 1920x1080 with 1024 spp and at
+               3840x2160 with 4096 spp, both whole frames at BASELINE's sizes — those two carry a roofline of the general-closure
+               shade kernel, k_shade_g.
 """
 import argparse
 import glob
@@ -397,7 +397,7 @@ def make_scene(scenes, kind, triangles, width, height):
     return scenes.multi_material_soup(triangles, seed=1234, width=width, height=height) if kind == "zoo" else scenes.soup(triangles, seed=1234, width=width, height=height)
 
 
-def run_workload(xpu, scenes, kind, triangles, width, height, spp, depth, seed, builder, steps, warmup, samples_in_flight=0, shard=(0, 1)):
+def run_workload(xpu, scenes, kind, triangles, width, height, spp, depth, seed, builder, steps, warmup, samples_in_flight=0, shard=(0, 1), host_pass=True):
     """one device, one scene, `steps` timed frames with the film in HBM, then `steps` more through the host film sink
     -> (value Mrays/s, ms per step, acc, last stats, preprocess s, scene, film, value through the host film)"""
     scene = make_scene(scenes, kind, triangles, width, height)
@@ -421,33 +421,36 @@ def run_workload(xpu, scenes, kind, triangles, width, height, spp, depth, seed, 
     elapsed = time.perf_counter() - t0
     film = film_dev.cpu().numpy()
     del film_dev
-    host = xpu.Film(width, height, 4)
-    rays_h = 0
-    for i in range(1 + steps):  # one warm-up frame sizes the pinned staging buffer
-        if i == 1:
-            t0 = time.perf_counter()
-        tiles.reset()
-        dev.start(scene, xpu.FrameState(seed, tiles, host, native_sink=True)); dev.join()
-        if i >= 1:
-            h = dev.stats(); rays_h += h["rays_closest"] + h["rays_shadow"]
-    value_host = rays_h / (time.perf_counter() - t0) / 1e6
+    value_host = None
+    if host_pass:
+        host = xpu.Film(width, height, 4)
+        rays_h = 0
+        for i in range(1 + steps):  # one warm-up frame sizes the pinned staging buffer
+            if i == 1:
+                t0 = time.perf_counter()
+            tiles.reset()
+            dev.start(scene, xpu.FrameState(seed, tiles, host, native_sink=True)); dev.join()
+            if i >= 1:
+                h = dev.stats(); rays_h += h["rays_closest"] + h["rays_shadow"]
+        value_host = rays_h / (time.perf_counter() - t0) / 1e6
     dev.close()
     return (acc["closest"] + acc["shadow"]) / elapsed / 1e6, elapsed * 1e3 / steps, acc, st, pre, scene, film, value_host
 
 
-def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, args, cpu_seconds, shard=(0, 1)):
+def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, args, cpu_seconds, shard=(0, 1), steps=2, warmup=1, host_pass=True):
     like = argparse.Namespace(triangles=triangles, width=width, height=height, depth=args.depth, spp=spp, seed=args.seed, cpu_spp=args.cpu_spp,
                               cpu_seconds=cpu_seconds)
-    value, ms, acc, st, pre, scene, film, value_host = run_workload(xpu, scenes, kind, triangles, width, height, spp, args.depth, args.seed, "auto", steps=2, warmup=1, shard=shard)
-    rec = {"workload": name, "value": value, "value_host_film": value_host, "unit": "Mrays/s", "ms_per_step": ms, "steps": 2, "rays_per_step": (acc["closest"] + acc["shadow"]) / 2,
+    value, ms, acc, st, pre, scene, film, value_host = run_workload(xpu, scenes, kind, triangles, width, height, spp, args.depth, args.seed, "auto", steps=steps, warmup=warmup, shard=shard,
+                                                                    host_pass=host_pass)
+    rec = {"workload": name, "value": value, "value_host_film": value_host, "unit": "Mrays/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "rays_per_step": (acc["closest"] + acc["shadow"]) / steps,
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"], "hbm_bytes": st["device_bytes"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
-           "kernel_ms_per_step": kernel_ms(acc, 2), "film_finite": bool(np.isfinite(film).all())}
+           "kernel_ms_per_step": kernel_ms(acc, steps), "film_finite": bool(np.isfinite(film).all())}
     tag = workload_tag(kind, triangles, width, height, args.depth)
     if kind == "zoo":
-        rec["roofline"] = shade_roofline(acc, 2, st, tag)
-        rec["roofline_k_trace"] = roofline(acc, 2, None, tag, None)
-        rec["primary"] = primary_record(acc, 2, None)
+        rec["roofline"] = shade_roofline(acc, steps, st, tag)
+        rec["roofline_k_trace"] = roofline(acc, steps, None, tag, None)
+        rec["primary"] = primary_record(acc, steps, None)
         return rec
     work = count_work(triangles, width, height, spp, "auto")
     ref_visits = None
@@ -793,12 +796,12 @@ def main(argv=None):
                                             "soup", 1000000, 1280, 720, 256, args, cpu_seconds=args.cpu_seconds))
                 sec.append(secondary_record(xpu, scenes, "Soup(10000000, seed 1234) 3840x2160 256 spp depth 9: the whole BASELINE config-4 frame on ONE GPU",
                                             "soup", 10000000, 3840, 2160, 256, args, cpu_seconds=0))
-                sec.append(secondary_record(xpu, scenes, "config-3 stand-in (no BMW scene ships with the reference): multi_material_soup(500000), 16 closure "
-                                            "recipes over all 7 lobe models, 1920x1080, 256 of 1024 spp, depth 9, whole frame on one GPU",
-                                            "zoo", 500000, 1920, 1080, 256, args, cpu_seconds=0))
-                sec.append(secondary_record(xpu, scenes, "config-5 stand-in: the same 16-recipe scene at 3840x2160 at the FULL 4096 spp on every 64th tile (127 of 8 160 tiles: one "
-                                            "batch of 130 k pixels x 4096 samples), depth 9 (the shading-bound regime: k_shade_g)",
-                                            "zoo", 500000, 3840, 2160, 4096, args, cpu_seconds=0, shard=(0, 64)))
+                sec.append(secondary_record(xpu, scenes, "BASELINE config 3 at its full size on a stand-in scene (no BMW scene ships with the reference): multi_material_soup(500000), "
+                                            "16 closure recipes over all 7 lobe models, 1920x1080, 1024 spp, depth 9, whole frame on one GPU",
+                                            "zoo", 500000, 1920, 1080, 1024, args, cpu_seconds=0))
+                sec.append(secondary_record(xpu, scenes, "BASELINE config 5 at its full size on the same stand-in scene: 3840x2160, 4096 spp, depth 9, the WHOLE frame on ONE GPU "
+                                            "(34 G camera samples; one timed frame, no warm-up frame, no host-film pass: the shading-bound regime, k_shade_g)",
+                                            "zoo", 500000, 3840, 2160, 4096, args, cpu_seconds=0, steps=1, warmup=0, host_pass=False))
                 out["secondary"] = sec
         else:
             out["cpu_baseline"] = None

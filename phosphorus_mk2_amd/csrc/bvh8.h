@@ -188,6 +188,9 @@ typedef float phx_f2 __attribute__((ext_vector_type(2)));
 #ifndef PHX_PAD_FMA
 #define PHX_PAD_FMA 1  /* the padded exit distance minus the entry distance as ONE fma (one instruction less per child; -0.3 ms of 47: profiles/r03_zz_pad_fma_ab.log) */
 #endif
+#ifndef PHX_BITOP3
+#define PHX_BITOP3 1
+#endif
 #ifndef PHX_F16_PLANES
 #define PHX_F16_PLANES 0  /* experiment, measured 4 % SLOWER (below) */
 #endif
@@ -263,7 +266,10 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
       const float tfz = fmaf((float)((farz >> sh) & 0xffu), az, bz);
       const float tn = fmaxf(fmaxf(tnx, tny), tnz);
       const float tf = fminf(fminf(tfx, tfy), tfz);
-#if PHX_PAD_FMA && PHX_NO_NEG_ZERO
+#if PHX_PAD_FMA && PHX_NO_NEG_ZERO && PHX_BITOP3
+      // the three-way OR as v_bitop3_b32 (truth table 0xfe): 2.2 clocks where v_or3_b32 takes 4.1 (profiles/r05_valu_ops.json)
+      const uint32_t m = __builtin_amdgcn_bitop3_b32(__float_as_uint(fmaf(tf, pad_far, -tn)), __float_as_uint(tmaxp - tn), __float_as_uint(tf), 0xfe);
+#elif PHX_PAD_FMA && PHX_NO_NEG_ZERO
       const uint32_t m = __float_as_uint(fmaf(tf, pad_far, -tn)) | __float_as_uint(tmaxp - tn) | __float_as_uint(tf);
 #elif PHX_PAD_FMA
       const uint32_t m = __float_as_uint(fmaf(tf, pad_far, -tn)) | __float_as_uint(tmaxp - tn) | __float_as_uint(tf + 0.0f);  // tf * pad - tn in one instruction

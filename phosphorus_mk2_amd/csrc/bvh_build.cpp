@@ -270,6 +270,10 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     // experiment knob (16 = cuts within 4 levels), clamped: the DP tables below hold 256 heap positions and a position h < limit
     // looks at its children 2h and 2h+1
     static const uint32_t dp_heap_limit = (uint32_t)std::min(128, std::max(2, getenv("PHX_DP_HEAP") ? atoi(getenv("PHX_DP_HEAP")) : 128));
+    // study knob (scripts/width_study.py, read per build): at most this many children per node — 4 gives the tree a 4-wide collapse of the
+    // same binary tree would have, in the same 64-byte nodelets (half of their slots empty): node visits and triangle tests of a
+    // narrower layout can be counted with the unchanged traversal
+    const int width = std::min(8, std::max(2, getenv("PHX_WIDTH") ? atoi(getenv("PHX_WIDTH")) : 8));
     struct Local {
       float best[256][9]; uint8_t split[256][9]; uint8_t done[256][9]; uint32_t node[256];
     };
@@ -308,8 +312,8 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
         return r;
       };
       float r = FLT_MAX; int bk = 1;
-      for (int k = 1; k < 8; ++k) {
-        const float t = best(2, M.left, k) + best(3, M.right, 8 - k);
+      for (int k = 1; k < width; ++k) {
+        const float t = best(2, M.left, k) + best(3, M.right, width - k);
         if (t < r) { r = t; bk = k; }
       }
       sub[m] = r;
@@ -317,7 +321,7 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
       Cut& C = cuts[m]; C.count = 0;
       struct Item { uint32_t h; int j; };
       Item st[16]; int top = 0;
-      st[top++] = Item{3, 8 - bk}; st[top++] = Item{2, bk};
+      st[top++] = Item{3, width - bk}; st[top++] = Item{2, bk};
       while (top > 0) {
         const Item it = st[--top];
         const uint8_t k = L.split[it.h][it.j];

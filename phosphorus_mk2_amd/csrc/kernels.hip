@@ -49,7 +49,7 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 // each other (two barriers and one atomic latency per workgroup instead of four and two).
 template <int SHADE_BLOCK>
 __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, bool want_b, uint32_t* counter_b, uint32_t* lds /* [2 * (waves + 1)] */,
-                                              uint32_t& at_a, uint32_t& at_b) {
+                                              uint32_t& at_a, uint32_t& at_b, unsigned long long* probe = nullptr /* PHX_SHADE_TIMING: ticks of the atomics' round trips, their number */) {
   static_assert(SHADE_BLOCK >= 128 && SHADE_BLOCK % 64 == 0, "block_append2: wave 0 sums queue A, wave 1 queue B");
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nwaves = SHADE_BLOCK >> 6;
   const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b);
@@ -61,7 +61,13 @@ __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, 
     uint32_t total = 0;
 #pragma nounroll
     for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = cnt[w]; cnt[w] = total; total += c; }
+#if PHX_SHADE_TIMING
+    const long long ta_ = clock64();
+#endif
     cnt[nwaves] = total ? atomicAdd(wave == 0 ? counter_a : counter_b, total) : 0u;
+#if PHX_SHADE_TIMING
+    if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); atomicAdd(&probe[0], (unsigned long long)(clock64() - ta_)); atomicAdd(&probe[1], 1ull); }
+#endif
   }
   __syncthreads();
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -934,6 +940,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_PHASE_DECL
 #define PHX_PHASE(n)
 #endif
+#ifndef PHX_SHADE_PREFETCH
+#define PHX_SHADE_PREFETCH 2  /* k_shade_g: 1 = hit record and ray of the next round are requested before this round's append; 2 = and path state + triangle record right after it (35.9 / 35.3 / 34.8 ms for 0 / 1 / 2: profiles/r05_c_shade_prefetch_ab.log) */
+#endif
 #ifndef PHX_SCALAR_F
 #define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
 #endif
@@ -967,27 +976,36 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #if PHX_SHADE_TIMING
   unsigned long long ph_rounds = 0, ph_windows = 0;
 #endif
+  // The sort keys of a window: two dependent gathers per hit — the hit record's triangle, that triangle's material.  (Fetching them one
+  // window AHEAD — the triangles while the last round of the previous window waits in its append, the materials right after it, parked in
+  // 4 KB of LDS — changed nothing: 34.6-35.1 ms either way, profiles/r05_c_shade_prefetch3_ab.log.)  0xfffffffe = slot past the end of the queue.
+  auto request_tris = [&](uint32_t b, uint32_t (&tri)[ITEMS]) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const uint32_t i = b + k * BLOCK + threadIdx.x;
+      tri[k] = i < count ? f2u(pb.hit[i].w) : 0xfffffffeu;
+    }
+  };
+  auto request_keys = [&](const uint32_t (&tri)[ITEMS], uint32_t (&key)[ITEMS]) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+#if PHX_SHADE_KEY_PROBE
+      key[k] = tri[k] == 0xfffffffeu ? NB + 1u : tri[k] != 0xffffffffu ? 0u : (uint32_t)NB;  // probe builds only: what the material gather of the sort phase costs (one-material scenes)
+#else
+      key[k] = tri[k] == 0xfffffffeu ? NB + 1u : tri[k] != 0xffffffffu ? (sc.tris[tri[k]].material & (NB - 1u)) : (uint32_t)NB;
+#endif
+    }
+  };
   for (uint32_t base = blockIdx.x * WINDOW; base < count; base += gridDim.x * WINDOW) {
     PHX_PHASE(5)  // (the barrier at the end of the previous window, loop overhead)
     // ---- counting sort of the window by material, through LDS
     if (threadIdx.x < NB + 2) bucket[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t keys[ITEMS], ranks[ITEMS];
+    uint32_t keys[ITEMS];
+    { uint32_t tri_[ITEMS]; request_tris(base, tri_); request_keys(tri_, keys); }
+    uint32_t ranks[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      const uint32_t i = base + k * BLOCK + threadIdx.x;
-      uint32_t key = NB + 1u;
-      if (i < count) {
-        const uint32_t tri = f2u(pb.hit[i].w);
-#if PHX_SHADE_KEY_PROBE
-        key = tri != 0xffffffffu ? 0u : (uint32_t)NB;  // probe builds only: what the material gather of the sort phase costs (one-material scenes)
-#else
-        key = tri != 0xffffffffu ? (sc.tris[tri].material & (NB - 1u)) : (uint32_t)NB;
-#endif
-      }
-      keys[k] = key;
-      ranks[k] = atomicAdd(&bucket[key], 1u);
-    }
+    for (int k = 0; k < ITEMS; ++k) ranks[k] = atomicAdd(&bucket[keys[k]], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {  // exclusive scan of the bucket counts by one wave
       const uint32_t c = bucket[threadIdx.x];
@@ -1006,12 +1024,51 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     ++ph_windows;
 #endif
     // ---- the window in sorted order: wave w of round k shades sorted positions [k * BLOCK + 64 w, + 64)
+    // The records of round k + 1 — hit, ray — are REQUESTED right before round k's append (PHX_SHADE_PREFETCH): the phase probe of round 5
+    // (profiles/r05_c_shade_phases.md) found a wave waiting 27 % of its time for exactly these loads and 24 % in the append (two barriers
+    // and the round trip of the workgroup's atomics); at the append a thread holds almost nothing but its outputs, so the twelve registers of
+    // the next records cost no occupancy there, and the two waits overlap.  (Round 3 requested them at the START of round k and held them
+    // across the closure code: 5-12 VGPRs where the kernel has none to spare, 1.2 of 42.7 ms: profiles/r03_q_prefetch_ab.log.)
+    uint32_t next_i = 0; bool next_live = false;
+    float4 next_h = make_float4(0.f, 0.f, 0.f, 0.f), next_a = next_h, next_b = next_h;
+    auto request_round = [&](int k) {
+      next_live = false;
+      if (k < ITEMS && base + (uint32_t)k * BLOCK < count) {
+        next_i = base + perm[k * BLOCK + threadIdx.x];
+        next_live = next_i < count;
+        if (next_live) {
+          next_h = pb.hit[next_i];
+          if (!FIRST) { next_a = pb.ro[q][next_i]; next_b = pb.rd[q][next_i]; }
+        }
+      }
+    };
+    // second stage (PHX_SHADE_PREFETCH 2): what depends on those records — the path state and the triangle record — is requested right
+    // after the append, when the first stage has landed, and travels while this round's queue entries are stored
+    float4 next_bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // FIRST: state_t::reset: beta = 1, depth = 0
+    TriRec next_T{};
+    auto request_round_dependents = [&]() {
+      if (next_live) {
+        if (!FIRST) next_bd = pb.pb[f2u(next_a.w) & 0x7fffffffu];
+        const uint32_t tri = f2u(next_h.w);
+        if (tri != 0xffffffffu) next_T = sc.tris[tri];
+      }
+    };
+#if PHX_SHADE_PREFETCH
+    request_round(0);
+#if PHX_SHADE_PREFETCH >= 2
+    request_round_dependents();
+#endif
+#endif
     for (int k = 0; k < ITEMS; ++k) {
       if (base + (uint32_t)k * BLOCK >= count) break;  // workgroup-uniform: the slots past the end of the queue sort behind every live one
-      const uint32_t i = base + perm[k * BLOCK + threadIdx.x];
-      const bool live = i < count;
-      // (Requesting the hit record and the ray of round k + 1 while round k is shaded — the window's order is fixed by then — costs
-      // 5-12 VGPRs and bought 1.2 of 42.7 ms: profiles/r03_q_prefetch_ab.log.  Not kept.)
+#if !PHX_SHADE_PREFETCH
+      request_round(k);
+#endif
+#if PHX_SHADE_PREFETCH < 2
+      request_round_dependents();
+#endif
+      const uint32_t i = next_i;
+      const bool live = next_live;
       // Live ranges are kept short on purpose (the kernel is register-bound: 128 VGPRs as one block of code): radiance and the
       // normals channel are written as soon as the hit is known; the light's record is re-read after the closure evaluation instead
       // of being held across it.
@@ -1021,19 +1078,19 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       uint32_t mat = 0;  // the hit's material: an INDEX — bsdf_f / bsdf_sample read the recipe through the scalar cache, one distinct material of the wave at a time
       if (live) {
         float4 a, b, bd;
-        const float4 h = pb.hit[i];
+        const float4 h = next_h;
         if (FIRST) {
           v3 co, cd;
           camera_ray(sc, pb, i, sample0, co, cd);
           a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
           bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
         } else {
-          a = pb.ro[q][i]; b = pb.rd[q][i];
+          a = next_a; b = next_b;
         }
         const uint32_t pbits = f2u(a.w);
         path = pbits & 0x7fffffffu;
         const bool specular = (pbits >> 31) != 0;
-        if (!FIRST) bd = pb.pb[path];
+        if (!FIRST) bd = next_bd;
         beta = v3(bd.x, bd.y, bd.z);
         depth = f2u(bd.w);
         const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
@@ -1044,7 +1101,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         v3 add_e(0.0f); bool add_rad = false;
         if (tri != 0xffffffffu) {
           hit_surface = true;
-          const TriRec T = sc.tris[tri];
+          const TriRec T = next_T;
           const uint32_t pm = T.material;
           p = o + d * h.x;            // hits.p = p + wi*d
           wo = -d;                    // hits.wi = -wi
@@ -1163,9 +1220,19 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
         PHX_PHASE(3)  // roulette, bsdf_sample, path state store
+#if PHX_SHADE_PREFETCH
+        request_round(k + 1);  // in flight across the append's barriers and atomics (the barriers wait for LDS traffic only)
+#endif
         uint32_t no, ns;
+        #if PHX_SHADE_TIMING
+        block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns, &pb.stats->idle_lane_iters);
+#else
         block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns);
+#endif
         PHX_PHASE(4)  // the append: two barriers and the workgroup's two atomics on the queue counters
+#if PHX_SHADE_PREFETCH >= 2
+        request_round_dependents();
+#endif
         if (want_shadow) {
           pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
           pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);

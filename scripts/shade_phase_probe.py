@@ -23,3 +23,4 @@ print("| phase | share of wave time | ticks per wave-round |")
 print("|---|---|---|")
 for n, t in zip(names, ph[:6]):
     print(f"| {n} | {t / tot:.3f} | {t / max(1, ph[6]):.0f} |")
+print(f"\nround trip of one queue-counter atomic (wave 0 / 1, lane 0; s_memtime around the returning atomicAdd): {st['idle_lane_iters'] / max(1, st['tri_pending_lane_iters']):.0f} ticks over {st['tri_pending_lane_iters']} atomics")

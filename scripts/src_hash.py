@@ -45,7 +45,7 @@ def priced_source_hash(path=BVH8):
         for b in bodies:
             h.update(name.encode() + b"\0" + re.sub(r"[ \t]+", " ", b).encode() + b"\0")
     # the switches that select the code path inside those functions
-    for m in re.finditer(r"^#define (PHX_(?:FAST_RCP|PACKED_FMA|SIGN_ACCUM|NO_NEG_ZERO|PAD_FMA|F16_PLANES|GRID_BITS))\b[ \t]*([^\n/]*)", src, re.M):
+    for m in re.finditer(r"^#define (PHX_(?:FAST_RCP|PACKED_FMA|SIGN_ACCUM|NO_NEG_ZERO|PAD_FMA|BITOP3|F16_PLANES|GRID_BITS))\b[ \t]*([^\n/]*)", src, re.M):
         h.update((m.group(1) + "=" + m.group(2).strip()).encode() + b"\0")
     return h.hexdigest()[:16]
 
