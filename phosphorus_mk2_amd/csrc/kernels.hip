@@ -1053,22 +1053,17 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         if (tri != 0xffffffffu) next_T = sc.tris[tri];
       }
     };
-#if PHX_SHADE_PREFETCH
-    request_round(0);
-#if PHX_SHADE_PREFETCH >= 2
-    request_round_dependents();
-#endif
-#endif
+    // (with per-hit closure weights — glass — either stage costs the kernel 16 B of scratch and buys nothing: 41.7-42.1 ms with, 41.9-42.2
+    // without on the glass showroom, profiles/r05_c_shade_prefetch_glass_ab.log: those instantiations request where they consume)
+    constexpr bool STAGE1 = PHX_SHADE_PREFETCH >= 1 && !PERHIT, STAGE2 = PHX_SHADE_PREFETCH >= 2 && !PERHIT;
+    if constexpr (STAGE1) request_round(0);
+    if constexpr (STAGE2) request_round_dependents();
     for (int k = 0; k < ITEMS; ++k) {
       if (base + (uint32_t)k * BLOCK >= count) break;  // workgroup-uniform: the slots past the end of the queue sort behind every live one
-#if !PHX_SHADE_PREFETCH
-      request_round(k);
-#endif
-#if PHX_SHADE_PREFETCH < 2
-      request_round_dependents();
-#endif
-      const uint32_t i = next_i;
-      const bool live = next_live;
+      // (instantiations without a stage request each record where it is consumed, exactly as the round-4 kernel did)
+      if constexpr (STAGE1 && !STAGE2) request_round_dependents();
+      const uint32_t i = STAGE1 ? next_i : base + perm[k * BLOCK + threadIdx.x];
+      const bool live = STAGE1 ? next_live : i < count;
       // Live ranges are kept short on purpose (the kernel is register-bound: 128 VGPRs as one block of code): radiance and the
       // normals channel are written as soon as the hit is known; the light's record is re-read after the closure evaluation instead
       // of being held across it.
@@ -1078,19 +1073,20 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       uint32_t mat = 0;  // the hit's material: an INDEX — bsdf_f / bsdf_sample read the recipe through the scalar cache, one distinct material of the wave at a time
       if (live) {
         float4 a, b, bd;
-        const float4 h = next_h;
+        float4 h;
+        if constexpr (STAGE1) h = next_h; else h = pb.hit[i];
         if (FIRST) {
           v3 co, cd;
           camera_ray(sc, pb, i, sample0, co, cd);
           a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
           bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
         } else {
-          a = next_a; b = next_b;
+          if constexpr (STAGE1) { a = next_a; b = next_b; } else { a = pb.ro[q][i]; b = pb.rd[q][i]; }
         }
         const uint32_t pbits = f2u(a.w);
         path = pbits & 0x7fffffffu;
         const bool specular = (pbits >> 31) != 0;
-        if (!FIRST) bd = next_bd;
+        if constexpr (!FIRST) { if constexpr (STAGE1) bd = next_bd; else bd = pb.pb[path]; }
         beta = v3(bd.x, bd.y, bd.z);
         depth = f2u(bd.w);
         const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
@@ -1101,7 +1097,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         v3 add_e(0.0f); bool add_rad = false;
         if (tri != 0xffffffffu) {
           hit_surface = true;
-          const TriRec T = next_T;
+          TriRec T;
+          if constexpr (STAGE1) T = next_T; else T = sc.tris[tri];
           const uint32_t pm = T.material;
           p = o + d * h.x;            // hits.p = p + wi*d
           wo = -d;                    // hits.wi = -wi
@@ -1220,9 +1217,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
         PHX_PHASE(3)  // roulette, bsdf_sample, path state store
-#if PHX_SHADE_PREFETCH
-        request_round(k + 1);  // in flight across the append's barriers and atomics (the barriers wait for LDS traffic only)
-#endif
+        if constexpr (STAGE1) request_round(k + 1);  // in flight across the append's barriers and atomics (the barriers wait for LDS traffic only)
         uint32_t no, ns;
         #if PHX_SHADE_TIMING
         block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns, &pb.stats->idle_lane_iters);
@@ -1230,9 +1225,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns);
 #endif
         PHX_PHASE(4)  // the append: two barriers and the workgroup's two atomics on the queue counters
-#if PHX_SHADE_PREFETCH >= 2
-        request_round_dependents();
-#endif
+        if constexpr (STAGE2) request_round_dependents();
         if (want_shadow) {
           pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
           pb.sd[ns] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t);
