@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 LIMIT=${PROFILE_LIMIT:-300}
-timeout -k 10 $LIMIT rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --one-sink $BENCH_ARGS > $OUT/stats.log 2>&1; echo "stats rc=$?"
-run() { name=$1; shift; timeout -k 10 $LIMIT rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --one-sink $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+timeout -k 10 $LIMIT rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --one-sink --full-json $OUT/stats_full.json $BENCH_ARGS > $OUT/stats.log 2>&1; echo "stats rc=$?"
+run() { name=$1; shift; timeout -k 10 $LIMIT rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --one-sink --full-json $OUT/${name}_full.json $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
