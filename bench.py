@@ -803,8 +803,8 @@ def main(argv=None):
                                             "16 closure recipes over all 7 lobe models, 1920x1080, 1024 spp, depth 9, whole frame on one GPU",
                                             "zoo", 500000, 1920, 1080, 1024, args, cpu_seconds=0))
                 sec.append(secondary_record(xpu, scenes, "BASELINE config 5 at its full size on the same stand-in scene: 3840x2160, 4096 spp, depth 9, the WHOLE frame on ONE GPU "
-                                            "(34 G camera samples; one timed frame after a warm-up on every 64th tile, no host-film pass: the shading-bound regime, k_shade_g)",
-                                            "zoo", 500000, 3840, 2160, 4096, args, cpu_seconds=0, steps=1, warmup=1, host_pass=False, warmup_shard=(0, 64)))
+                                            "(34 G camera samples; one timed frame after a warm-up on every 32nd tile — two batches, one of them full-size — no host-film pass: the shading-bound regime, k_shade_g)",
+                                            "zoo", 500000, 3840, 2160, 4096, args, cpu_seconds=0, steps=1, warmup=1, host_pass=False, warmup_shard=(0, 32)))
                 out["secondary"] = sec
         else:
             out["cpu_baseline"] = None

@@ -760,12 +760,19 @@ int phx_device::run_frame() {
   // (divided by the samples a pass will really carry: with an explicit samples_in_flight only P x S paths are ever in flight)
   const uint32_t pass_samples = std::max(1u, std::min(opt.samples_per_pixel, opt.samples_in_flight ? opt.samples_in_flight : opt.samples_per_pixel));
   const uint64_t pixel_cap = std::min<uint64_t>(8u << 20, std::max<uint64_t>(path_budget(path_bytes) / pass_samples, 64u << 10));
+  // A batch never EXCEEDS the cap (the tile that would is kept for the next batch): its paths then fit the queues the first full batch
+  // allocated, whatever mix of whole and edge tiles it holds.  (Until round 5 a batch overshot by up to one tile; a 4 096-spp batch that grew
+  // from 131 072 to 131 584 pixels re-allocated 86 GB of queues — 2.6 s of hipFree — in the middle of a frame: profiles/r05_f_c5_batch_probe.log.)
+  phx_tile held{}; bool have_held = false;
   for (;;) {
     std::vector<phx_tile> tiles;
     uint64_t px = 0;
-    phx_tile t;
-    while ((opt.tiles_per_batch == 0 || tiles.size() < opt.tiles_per_batch) && px < pixel_cap && frame.next_tile(frame.tiles_user, &t)) {
+    while ((opt.tiles_per_batch == 0 || tiles.size() < opt.tiles_per_batch) && px < pixel_cap) {
+      phx_tile t;
+      if (have_held) { t = held; have_held = false; }
+      else if (!frame.next_tile(frame.tiles_user, &t)) break;
       if (t.w == 0 || t.h == 0 || (uint64_t)t.x + t.w > scene.width || (uint64_t)t.y + t.h > scene.height) return fail(PHX_ERR_ARG, "tile outside the film");
+      if (!tiles.empty() && px + (uint64_t)t.w * t.h > pixel_cap) { held = t; have_held = true; break; }
       tiles.push_back(t); px += (uint64_t)t.w * t.h;
     }
     if (tiles.empty()) break;
@@ -811,6 +818,9 @@ int phx_device::run_frame() {
 int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vector<float2>& jit) {
   (void)jit;
   int rc;
+  static const bool host_timing = std::getenv("PHX_HOST_TIMING") != nullptr;  // probe: where a batch's host time goes
+  const auto tb0 = std::chrono::steady_clock::now();
+  auto tb_alloc = tb0, tb_enq = tb0;
   uint32_t P = 0;
   for (auto& t : tiles) P += t.w * t.h;
   const uint32_t spp = opt.samples_per_pixel;
@@ -865,6 +875,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     S = std::min((S + 1) / 2, std::min(pick_samples(), spp));
   }
   paths_in_flight = npaths;
+  tb_alloc = std::chrono::steady_clock::now();
 
   PassBuffers B{};
   for (int q = 0; q < 2; ++q) { B.ro[q] = ro[q].p; B.rd[q] = rd[q].p; }
@@ -877,6 +888,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   BatchLaunches* G = &direct;
   direct.events_used = 0; direct.timed.clear();
   if ((rc = enqueue_batch(direct, B, P, S, xs))) return rc;
+  tb_enq = std::chrono::steady_clock::now();
   if (frame.add_tile || frame.host_film) {
     const size_t nfl = (size_t)P * xs;
     if (nfl > h_acc_n) {
@@ -911,6 +923,11 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
     }
   } else {
     HIPCHK(hipStreamSynchronize(stream));
+  }
+  if (host_timing) {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "batch of %u px x %u samples: tables + allocation %.3f ms, enqueue %.3f, wait + sink %.3f\n", P, S, ms(tb0, tb_alloc), ms(tb_alloc, tb_enq),
+                 ms(tb_enq, std::chrono::steady_clock::now()));
   }
   // the batch is complete: its launches' HIP-event times (the next batch records the same events again)
   for (auto& te : G->timed) {
