@@ -448,7 +448,10 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
     rec = {"workload": name, "value": value, "value_host_film": value_host, "unit": "Mrays/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "rays_per_step": (acc["closest"] + acc["shadow"]) / steps,
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"], "hbm_bytes": st["device_bytes"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
-           "kernel_ms_per_step": kernel_ms(acc, steps), "film_finite": bool(np.isfinite(film).all())}
+           "kernel_ms_per_step": kernel_ms(acc, steps), "film_finite": bool(np.isfinite(film).all()),
+           # (general-closure scenes: the reference's li() has no guard for a light sample seen edge-on, SURVEY A-7 — at 4 096 spp a few pixels of 8 M
+           # collect an inf / NaN sample exactly as the reference's would; the parity tests compare the finite pixels and the non-finite MASK)
+           "film_finite_fraction": float(np.isfinite(film).all(-1).mean())}
     tag = workload_tag(kind, triangles, width, height, args.depth)
     if kind == "zoo":
         rec["roofline"] = shade_roofline(acc, steps, st, tag)
