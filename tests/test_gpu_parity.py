@@ -904,6 +904,25 @@ def test_watchdog_fails_the_frame_instead_of_hanging(xpu, orc):
     assert st["rays_closest"] == ost["rays_closest"] and bits_equal(film[..., :3], ref[..., :3])
 
 
+def test_frames_without_kernel_timing_render_the_same_film(xpu):
+    """PHX_KERNEL_TIMING=0 (a probe knob, read once per process): no HIP events between the launches — phx_stats carries no kernel times,
+    the film and the ray counts are the ones of a timed frame"""
+    import hashlib, os, subprocess, sys
+    from conftest import ROOT
+    from phosphorus_mk2_amd import scenes
+    want, wst = xpu.render(scenes.soup(3000, width=96, height=64), spp=9, seed=4)
+    assert wst["closest_ms"] > 0 and wst["shade_kernel_ms"] > 0 and wst["trace_launches"] == 9
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from phosphorus_mk2_amd import scenes, xpu\n"
+            "film, st = xpu.render(scenes.soup(3000, width=96, height=64), spp=9, seed=4)\n"
+            "print('R', hashlib.sha1(film.tobytes()).hexdigest(), st['rays_closest'], st['rays_shadow'], st['closest_ms'], st['shade_ms'], st['trace_launches'])\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, PHX_KERNEL_TIMING="0"))
+    assert r.returncode == 0, r.stderr[-500:]
+    f = [l for l in r.stdout.splitlines() if l.startswith("R ")][0].split()
+    assert f[1] == hashlib.sha1(want.tobytes()).hexdigest() and int(f[2]) == wst["rays_closest"] and int(f[3]) == wst["rays_shadow"]
+    assert float(f[4]) == 0.0 and float(f[5]) == 0.0 and int(f[6]) == 0
+
+
 def test_4k_film_in_several_batches(xpu, orc):
     """BASELINE config #4 shape of the film (3840x2160: more pixels than one tile batch holds, so the frame is rendered in
     several batches) with the normals channel on; tiles from every batch are compared with the oracle bit for bit."""
