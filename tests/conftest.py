@@ -41,6 +41,7 @@ def host_bvh8():
     lib.hb8_trace.argtypes = [C.c_void_p, C.c_uint32, abi.f32p, abi.f32p, abi.f32p, C.c_int, abi.f32p, abi.f32p, abi.f32p, abi.u32p,
                               C.POINTER(C.c_uint64)]
     lib.hb8_trace.restype = C.c_int
+    lib.hb8_trace_any_ordered.argtypes = [C.c_void_p, C.c_uint32, abi.f32p, abi.f32p, abi.f32p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
     return lib
 
 

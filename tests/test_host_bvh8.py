@@ -136,3 +136,38 @@ def test_degenerate_inputs(host_bvh8):
     r = trace(host_bvh8, h, np.array([[0, 1, -2], [0, 0.5, 0]], np.float32), np.array([[0, -1, 0], [0, 0, -1]], np.float32), np.array([1e30, 1e30], np.float32))
     assert r["prim"][0] != 0xffffffff and r["prim"][1] == 0xffffffff
     host_bvh8.hb8_free(h)
+
+
+def test_any_hit_answers_do_not_depend_on_the_visiting_order(host_bvh8):
+    """the study walk of scripts/width_study.py (tests/native/host_bvh8.cpp: hb8_trace_any_ordered): an any-hit ray is occluded or it is
+    not, whichever child of a node is visited first — octant order (the product's), largest first, smallest first — only the work differs;
+    and the PHX_WIDTH study knob (a 4-wide collapse of the same binary tree) changes the tree, not a single closest hit"""
+    import os
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(20000, width=32, height=32)
+    abc = tri_abc(sc)
+    h = host_bvh8.hb8_build(fp(abc), len(abc), 4)
+    o, d, _ = random_rays(8000, 23)
+    tm = np.full(len(o), 0.3, np.float32)
+    ref = trace(host_bvh8, h, o, d, tm, any_hit=True)
+    want = ref["prim"] != 0xffffffff
+    work = {}
+    for order in (0, 1, 2):
+        occ = np.zeros(len(o), np.uint8); ctr = (C.c_uint64 * 2)()
+        host_bvh8.hb8_trace_any_ordered(h, len(o), fp(o), fp(d), fp(tm), order, occ.ctypes.data_as(C.POINTER(C.c_uint8)), ctr)
+        assert np.array_equal(occ.astype(bool), want), order
+        work[order] = (ctr[0], ctr[1])
+    assert 0.2 < want.mean() < 0.98 and work[0][0] > 0 and work[1] != work[0]
+    full = trace(host_bvh8, h, o, d, np.full(len(o), np.finfo(np.float32).max, np.float32))
+    info8 = (C.c_uint64 * 3)(); host_bvh8.hb8_info(h, info8)
+    host_bvh8.hb8_free(h)
+    os.environ["PHX_WIDTH"] = "4"
+    try:
+        h4 = host_bvh8.hb8_build(fp(abc), len(abc), 4)
+    finally:
+        del os.environ["PHX_WIDTH"]
+    info4 = (C.c_uint64 * 3)(); host_bvh8.hb8_info(h4, info4)
+    narrow = trace(host_bvh8, h4, o, d, np.full(len(o), np.finfo(np.float32).max, np.float32))
+    host_bvh8.hb8_free(h4)
+    assert info4[0] > 1.5 * info8[0] and info4[1] == info8[1] == len(abc) and info4[2] > info8[2]  # more, narrower nodes; every triangle once
+    assert np.array_equal(full["prim"], narrow["prim"]) and bits_equal(full["t"], narrow["t"]) and narrow["node_visits"] > full["node_visits"]
