@@ -1,0 +1,73 @@
+// Micro-benchmark (round 5): the shade kernels' shape — a 1 024-thread workgroup reads 1 024 records, decides per record whether it
+// survives (85 %) and whether it sends a shadow ray (55 %), reserves slots in two output queues with ONE returning atomic per queue
+// between two barriers (kernels.hip: block_append2) and writes 2 + 3 records per slot plus one by path — with the queue counters
+//   mode 0: one counter per queue (the product)
+//   mode 1: K counters per queue, counter (workgroup id % K) owns every K-th slab of 1 024 slots of the same queue ("striped")
+//   mode 2: no atomics at all (slot = own index: what the streams alone cost)
+// make -C scripts/micro append_rate && scripts/micro/append_rate
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+__device__ __forceinline__ unsigned mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) k(const float4* in, float4* a0, float4* a1, float4* s0, float4* s1, float4* s2, float4* pr, unsigned* ctr, unsigned K) {
+  __shared__ unsigned cnt[2][17];
+  const unsigned i = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const float4 v = in[i];
+  const unsigned h = mix(i);
+  const bool alive = (h & 0xffu) < 218u, shadow = ((h >> 8) & 0xffu) < 141u;
+  const unsigned long long ma = __ballot(alive), mb = __ballot(shadow);
+  if (lane == 0) { cnt[0][wave] = (unsigned)__popcll(ma); cnt[1][wave] = (unsigned)__popcll(mb); }
+  __syncthreads();
+  if (lane == 0 && wave < 2) {
+    unsigned total = 0;
+    for (unsigned w = 0; w < 16; ++w) { const unsigned c = cnt[wave][w]; cnt[wave][w] = total; total += c; }
+    unsigned base;
+    if (MODE == 2) base = blockIdx.x * 1024u;
+    else {
+      const unsigned c = MODE == 1 ? blockIdx.x % K : 0u;
+      const unsigned t = atomicAdd(&ctr[(wave * 64u + c) * 32u], total);  // ticket of the first slot
+      // striped: ticket t of counter c -> slab (t / 1024) * K + c (the few slots that spill into the next slab are ignored by this benchmark's addressing)
+      base = MODE == 1 ? ((t >> 10) * K + c) * 1024u + (t & 1023u) : t;
+    }
+    cnt[wave][16] = base;
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned na = cnt[0][16] + cnt[0][wave] + (unsigned)__popcll(ma & below), ns = cnt[1][16] + cnt[1][wave] + (unsigned)__popcll(mb & below);
+  pr[i] = make_float4(v.x, v.y, v.z, 0.f);
+  if (alive) { a0[na] = make_float4(v.x + 1, v.y, v.z, v.w); a1[na] = make_float4(v.y, v.x, v.z, v.w); }
+  if (shadow) { s0[ns] = make_float4(v.z, v.y, v.x, v.w); s1[ns] = make_float4(v.w, v.y, v.z, v.x); s2[ns] = make_float4(v.x, v.z, v.y, v.w); }
+}
+
+template <int MODE>
+static double run(const float4* in, float4** o, unsigned* ctr, unsigned blocks, unsigned K) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  double best = 1e30;
+  for (int rep = 0; rep < 4; ++rep) {
+    (void)hipMemset(ctr, 0, 128 * 32 * 4);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(1024), 0, 0, in, o[0], o[1], o[2], o[3], o[4], o[5], ctr, K);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+
+int main() {
+  const unsigned blocks = 230400;  // 236 M records: the bench frame's camera paths
+  const size_t bytes = (size_t)blocks * 1024 * 16 + (64u << 20);
+  float4* in; float4* o[6]; unsigned* ctr;
+  (void)hipMalloc((void**)&in, bytes); (void)hipMemset(in, 0, bytes);
+  for (int a = 0; a < 6; ++a) (void)hipMalloc((void**)&o[a], bytes);
+  (void)hipMalloc((void**)&ctr, 128 * 32 * 4);
+  std::printf("{\"records\": %u, \"unit\": \"ms for one pass (16 B read + 16 B by path + 0.85 x 32 B + 0.55 x 48 B written per record: %.1f GB)\",\n", blocks * 1024u,
+              blocks * 1024.0 * (16 + 16 + 0.85 * 32 + 0.55 * 48) / 1e9);
+  std::printf("  \"no atomics\": %.3f,\n  \"one counter per queue\": %.3f,\n", run<2>(in, o, ctr, blocks, 1), run<0>(in, o, ctr, blocks, 1));
+  for (unsigned K : {2u, 4u, 8u, 16u, 64u}) std::printf("  \"%u striped counters per queue\": %.3f,\n", K, run<1>(in, o, ctr, blocks, K));
+  std::printf("  \"one counter per queue (again)\": %.3f}\n", run<0>(in, o, ctr, blocks, 1));
+  return 0;
+}
