@@ -796,6 +796,8 @@ def main(argv=None):
             out["config"]["gpu_over_cpu"] = value / base["value"]
             out["roofline"] = roofline(acc, args.steps, work, workload_tag("soup", args.triangles, W, H, args.depth), ref_visits)
             out["primary"] = primary_record(acc, args.steps, work)
+            # the frame's second kernel by time, k_shade (Lambert scenes): HBM-stream roofline by algorithmic bytes, counters from the same capture (full record only)
+            out["roofline_shade"] = shade_roofline(acc, args.steps, st, workload_tag("soup", args.triangles, W, H, args.depth))
             if not args.no_secondary and (args.triangles, W, H, args.spp) == (100000, 1280, 720, 256):
                 sec = []
                 sec.append(secondary_record(xpu, scenes, "Soup(1000000, seed 1234) 1280x720 256 spp depth 9 (north star's target scene)",
