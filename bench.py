@@ -326,8 +326,9 @@ def roofline(acc, steps, work, tag, ref_visits):
 
 
 # algorithmic bytes per shaded queue entry in the device's layout: in — hit 16, ray 32, path state 16,
-# triangle record 64 (one 64-B element of the pool); out — next ray 32 + path state 16 for a survivor, 48 for an NEE ray
-SHADE_BYTES_IN, SHADE_BYTES_SURVIVOR, SHADE_BYTES_NEE = 16 + 32 + 16 + 64, 32 + 16, 48
+# triangle record 64 (one 64-B element of the pool); out — next ray 32 + path state 16 for a survivor, 48 for an NEE ray.
+# The camera rays' entries (the first launch of a pass) read no ray and no path state — both are rebuilt — and write the path's radiance (16).
+SHADE_BYTES_IN, SHADE_BYTES_IN_CAMERA, SHADE_BYTES_SURVIVOR, SHADE_BYTES_NEE = 16 + 32 + 16 + 64, 16 + 64 + 16, 32 + 16, 48
 
 
 def shade_roofline(acc, steps, st, tag):
@@ -338,7 +339,7 @@ def shade_roofline(acc, steps, st, tag):
     t = acc["shade_kernel_ms"] * 1e-3
     entries, nee = acc["closest"], acc["shadow"]
     survivors = max(0, acc["closest"] - acc["camera"])  # every closest-hit ray after the camera rays is a survivor of a shade launch
-    alg = entries * SHADE_BYTES_IN + survivors * SHADE_BYTES_SURVIVOR + nee * SHADE_BYTES_NEE
+    alg = acc["camera"] * SHADE_BYTES_IN_CAMERA + survivors * SHADE_BYTES_IN + survivors * SHADE_BYTES_SURVIVOR + nee * SHADE_BYTES_NEE
     kernel = "k_shade_g" if st.get("shade_general") else "k_shade"
     roof = {"kernel": kernel, "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "launches_per_step": nl / steps, "avg_launch_ms": t * 1e3 / nl, "entries_per_launch": entries / nl,
