@@ -178,7 +178,7 @@ def workload_tag(kind, triangles, width, height, depth=9):
     if depth != 9:
         return None
     return {("soup", 100000, 1280, 720): "100k", ("soup", 1000000, 1280, 720): "1M", ("soup", 10000000, 3840, 2160): "c4",
-            ("zoo", 500000, 1920, 1080): "zoo", ("zoo", 500000, 3840, 2160): "zoo4k"}.get((kind, triangles, width, height))
+            ("zoo", 500000, 1920, 1080): "zoo", ("zoo", 500000, 3840, 2160): "zoo4k", ("room", 500000, 1920, 1080): "room"}.get((kind, triangles, width, height))
 
 
 def priced_source_hash():
@@ -284,19 +284,31 @@ def roofline(acc, steps, work, tag, ref_visits):
     peak, peak_src, peak_refused = committed_valu_peak()
     roof["timing"] = ("HIP events on the device's own stream, ONE event between consecutive launches: a launch's time includes the few "
                       "microseconds since the previous kernel ended")
+    cap, src = load_capture(tag)
+    D = capture_diagnostics(cap, src, "k_trace", rays_c + rays_s) if cap else None  # the captures render this same frame once
     if work and "error" not in work and not peak:
         roof["frac_unavailable"] = peak_refused
     if work and "error" not in work and peak:
         nv = sum(work[k]["rays"] * (work[k]["node_visits_lds_per_ray"] + work[k]["node_visits_mem_per_ray"]) for k in ("closest", "shadow"))
         tt = sum(work[k]["rays"] * work[k]["tri_tests_per_ray"] for k in ("closest", "shadow"))
-        t_min = nv / peak["node_tests_per_s"] + tt / peak["tri_tests_per_s"]
+        # The peak is a rate PER SECOND measured at the micro-benchmark's shader clock (2.3-2.4 GHz: nothing but VALU work); k_trace itself runs
+        # at ~2.2 GHz (GRBM_GUI_ACTIVE of its own capture).  The ceiling of the arithmetic AT THE CLOCK THE KERNEL RUNS AT is the per-clock rate
+        # x that clock; without a capture of this workload the micro-benchmark's own clock stands and the record says so.
+        k_clock, p_clock = (D or {}).get("clock_hz"), peak.get("clock_hz")
+        scale = (k_clock / p_clock) if (k_clock and p_clock and (D or {}).get("clock_source", "").startswith("GRBM")) else 1.0
+        node_rate, tri_rate = peak["node_tests_per_s"] * scale, peak["tri_tests_per_s"] * scale
+        t_min = nv / node_rate + tt / tri_rate
         roof.update({"achieved": nv / t_frame / 1e9, "peak": nv / t_min / 1e9, "frac": t_min / t_frame})
         roof["work"] = {"node_visits_per_frame": nv, "tri_tests_per_frame": tt, "min_alu_ms_per_frame": t_min * 1e3, "k_trace_ms_per_frame": t_frame * 1e3,
-                        "peak_node_tests_per_s": peak["node_tests_per_s"], "peak_tri_tests_per_s": peak["tri_tests_per_s"], "peak_source": peak_src,
-                        "peak_src_hash": peak.get("src_hash"), "peak_clock_hz": peak.get("clock_hz"),
+                        "peak_node_tests_per_s": node_rate, "peak_tri_tests_per_s": tri_rate, "peak_source": peak_src,
+                        "peak_src_hash": peak.get("src_hash"), "peak_clock_hz": p_clock, "kernel_clock_hz": k_clock if scale != 1.0 else None, "peak_clock_scale": scale,
+                        "peak_node_tests_per_s_at_micro_clock": peak["node_tests_per_s"], "peak_tri_tests_per_s_at_micro_clock": peak["tri_tests_per_s"],
+                        "peak_asm_check": peak.get("asm_check"),
                         "lanes_per_node_block": work["wave"]["lanes_per_node_block"], "lanes_per_tri_block": work["wave"]["lanes_per_tri_block"],
                         "what": "node visits + triangle tests of this frame (instrumented build, this run) priced at the chip's rate for k_trace's own "
-                                "arithmetic alone (all 64 lanes active, operands in registers) = minimum ALU time / k_trace time of this run"}
+                                "arithmetic alone (all 64 lanes active, operands in registers; the micro-benchmark's loop is checked against the kernel's "
+                                "assembly: same 48 conversions, VALU count within 5 %), at the shader clock k_trace itself ran at in its capture "
+                                "= minimum ALU time / k_trace time of this run"}
         # bytes this kernel's own layout moves per ray: 64-B nodelets through the L1 (LDS-staged ones are free), 48 B of a triangle
         # record, ray in (32 B closest, 48 B shadow incl. its beta*Li), result out (16 B hit record; 32 B radiance read-modify-write)
         dl = {}
@@ -307,13 +319,10 @@ def roofline(acc, steps, work, tag, ref_visits):
                                  "visits_per_ray": {k: {x: work[k][x] for x in ("node_visits_lds_per_ray", "node_visits_mem_per_ray", "tri_tests_per_ray")} for k in ("closest", "shadow")}}
     elif work and "error" in work:
         roof["instrumented_pass_error"] = work["error"]
-    cap, src = load_capture(tag)
-    if cap:
-        D = capture_diagnostics(cap, src, "k_trace", rays_c + rays_s)  # the captures render this same frame once
-        if D:
-            roof["diagnostics"] = D
-            if "hbm" in D:
-                roof["traffic"] = D["hbm"]["bytes_per_launch"]
+    if D:
+        roof["diagnostics"] = D
+        if "hbm" in D:
+            roof["traffic"] = D["hbm"]["bytes_per_launch"]
     if ref_visits:
         (vn, vl), (vns, vls) = ref_visits["closest"], ref_visits["shadow"]
         b_ray, b_shadow = 56.0 + vn * 288.0 + vl * 384.0, 36.0 + vns * 288.0 + vls * 384.0
@@ -395,6 +404,8 @@ def add_stats(acc, st):
 
 
 def make_scene(scenes, kind, triangles, width, height):
+    if kind == "room":  # the closed showroom: mesh geometry, three decades of triangle sizes, 16 recipes + two glass materials (per-hit closure weights)
+        return scenes.bmw_showroom(triangles, width=width, height=height)
     return scenes.multi_material_soup(triangles, seed=1234, width=width, height=height) if kind == "zoo" else scenes.soup(triangles, seed=1234, width=width, height=height)
 
 
@@ -450,11 +461,15 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"], "hbm_bytes": st["device_bytes"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
            "kernel_ms_per_step": kernel_ms(acc, steps), "film_finite": bool(np.isfinite(film).all()),
-           # (general-closure scenes: the reference's li() has no guard for a light sample seen edge-on, SURVEY A-7 — at 4 096 spp a few pixels of 8 M
-           # collect an inf / NaN sample exactly as the reference's would; the parity tests compare the finite pixels and the non-finite MASK)
-           "film_finite_fraction": float(np.isfinite(film).all(-1).mean())}
+           # (general-closure scenes at thousands of samples per pixel: a few pixels of 8 M collect ONE non-finite sample.  Where: listed here,
+           # so that their tiles can be rendered with the oracle — scripts/nonfinite_probe.py does, and the masks must be equal: the sample is the
+           # restated arithmetic's, not the device's.  NOT "a light seen edge-on": |n_L . wi| = 0 gives pdf = inf and a ZERO contribution, in
+           # li() (spt.hpp:253-255) and here; a non-finite value needs a non-finite f or a pdf of 0)
+           "film_finite_fraction": float(np.isfinite(film).all(-1).mean()),
+           "nonfinite_pixels_xy": [[int(x), int(y)] for y, x in np.argwhere(~np.isfinite(film).all(-1))[:32]]}
     tag = workload_tag(kind, triangles, width, height, args.depth)
-    if kind == "zoo":
+    if kind in ("zoo", "room"):
+        rec["rays_per_camera_sample"] = (acc["closest"] + acc["shadow"]) / max(1, acc["camera"])
         rec["roofline"] = shade_roofline(acc, steps, st, tag)
         rec["roofline_k_trace"] = roofline(acc, steps, None, tag, None)
         rec["primary"] = primary_record(acc, steps, None)
@@ -573,11 +588,22 @@ def compact_line(full, full_path):
     if "kernel_ms_per_step" in c:
         out["config"]["kernel_ms_per_step"] = {k: _r(v, 4) for k, v in c["kernel_ms_per_step"].items()}
     out["roofline"] = compact_roofline(full.get("roofline"))
+    def by_counters(rf):  # HBM fraction from the committed capture's counters (FETCH x 2 + WRITE over the kernel's time in that capture)
+        hbm = ((rf or {}).get("diagnostics") or {}).get("hbm")
+        return _r(hbm["frac"], 4) if hbm else None
+    rs = full.get("roofline_shade")
+    if rs:  # the frame's second kernel: by algorithmic bytes (counts a 64-B triangle record per entry that comes from L2) AND by counters
+        out["roofline_shade"] = {"kernel": rs["kernel"], "bound": rs["bound"], "frac": _r(rs["frac"], 4), "frac_by_counters": by_counters(rs)}
     cb = full.get("cpu_baseline")
-    out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None
+    if cb:
+        out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample")}
+        out["cpu_baseline"]["cores_of"] = f"{cb['cores']} threads on a {cb['host']['cpu_share']:g}-CPU share of {cb['host']['hardware_threads']} hardware threads"
+    else:
+        out["cpu_baseline"] = None
     if full.get("secondary"):
-        out["secondary"] = [{"workload": s["workload"][:72], "value": _r(s["value"]), "ms_per_step": _r(s["ms_per_step"], 5),
-                             "roofline": {"kernel": s["roofline"]["kernel"], "bound": s["roofline"]["bound"], "frac": _r(s["roofline"]["frac"], 4)}}
+        out["secondary"] = [{"workload": s["workload"][:64], "value": _r(s["value"]), "ms_per_step": _r(s["ms_per_step"], 5),
+                             "roofline": {"kernel": s["roofline"]["kernel"], "bound": s["roofline"]["bound"], "frac": _r(s["roofline"]["frac"], 4),
+                                          **({"frac_by_counters": by_counters(s["roofline"])} if s["roofline"]["bound"] == "hbm" else {})}}
                             for s in full["secondary"]]
     out["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
     line = json.dumps(out)
@@ -808,6 +834,9 @@ def main(argv=None):
                 sec.append(secondary_record(xpu, scenes, "BASELINE config 3 at its full size on a stand-in scene (no BMW scene ships with the reference): multi_material_soup(500000), "
                                             "16 closure recipes over all 7 lobe models, 1920x1080, 1024 spp, depth 9, whole frame on one GPU",
                                             "zoo", 500000, 1920, 1080, 1024, args, cpu_seconds=0))
+                sec.append(secondary_record(xpu, scenes, "BASELINE config 3 at its full size on MESH geometry: bmw_showroom(500000) — closed room, 24 tessellated spheres, triangle sizes over three decades, "
+                                            "the 16 recipes + sharp and frosted glass (per-hit closure weights: k_shade_g<PERHIT>) — 1920x1080, 1024 spp, depth 9, whole frame on one GPU",
+                                            "room", 500000, 1920, 1080, 1024, args, cpu_seconds=0))
                 sec.append(secondary_record(xpu, scenes, "BASELINE config 5 at its full size on the same stand-in scene: 3840x2160, 4096 spp, depth 9, the WHOLE frame on ONE GPU "
                                             "(34 G camera samples; one timed frame after a warm-up on every 32nd tile — two batches, one of them full-size — no host-film pass: the shading-bound regime, k_shade_g)",
                                             "zoo", 500000, 3840, 2160, 4096, args, cpu_seconds=0, steps=1, warmup=1, host_pass=False, warmup_shard=(0, 32)))

@@ -248,7 +248,9 @@ int         phx_dev_preprocess(phx_device* dev, const phx_scene* scene);
 int         phx_dev_start(phx_device* dev, const phx_frame* frame);
 /* xpu_t::join (src/xpu.hpp:32; cpu.cpp:240): blocks; returns the frame's status. */
 int         phx_dev_join(phx_device* dev);
-/* ~xpu_t */
+/* ~xpu_t.  A frame that was started and not joined is JOINED here: destroy blocks until that frame has ended, and the frame's
+ * next_tile / add_tile callbacks may still be called while it does — whatever they use must outlive this call.  The device's driver
+ * thread (one per device, asleep between frames) ends with it; a device that is never destroyed leaves that thread asleep at exit. */
 void        phx_dev_destroy(phx_device* dev);
 
 /* last error message of the calling thread (a frame's error is handed to the thread that calls phx_dev_join) */

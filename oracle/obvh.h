@@ -31,6 +31,7 @@ static const uint32_t F_HIT = 1, F_MASKED = 2, F_SHADOW = 4, F_SPECULAR = 8;  //
 
 // numeric modes (SURVEY §7 hard part 2)
 inline int& scalar_default() { static int v = 0; return v; }
+inline int& debug_nonfinite() { static int v = 0; return v; }  // orc_set_debug_nonfinite: orender.cpp reports where a non-finite value enters a path
 inline int& tie_default() { static int v = 0; return v; }     // process-wide default of modes_t::tie_lowest_prim (orc_set_tie_rule)  // process-wide default of modes_t::scalar (orc_set_scalar)
 struct modes_t {
   int rcp_approx = 0;   // 1: use the x86 RCPPS approximation where the reference does (this CPU only)

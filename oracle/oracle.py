@@ -110,6 +110,11 @@ def set_tie_rule(lowest_prim):
     load().orc_set_tie_rule(1 if lowest_prim else 0)
 
 
+def set_debug_nonfinite(on):
+    """diagnostic: the renderer prints to stderr where a non-finite value enters a path (li() / the throughput update); results unchanged"""
+    load().orc_set_debug_nonfinite(1 if on else 0)
+
+
 def probe_soup(n):
     """(n, 9) float32 triangles of the soup the survey's probe rendered with the real reference:
     std::mt19937(1234) + std::uniform_real_distribution<float>(-1, 1), 12 draws per triangle."""

@@ -317,7 +317,11 @@ struct tile_renderer_t {
     const V3 light_n = mesh.shading_normal(rays.face[to], rays.u[to], rays.v[to]);
     const V3 le(lm.emission[0], lm.emission[1], lm.emission[2]);
     const float pdf = st.pdf[to] * d * d / std::fabs(light_n.dot(-wi));
-    return (le * 4.0f) * f * (1.0f / pdf);
+    const V3 r = (le * 4.0f) * f * (1.0f / pdf);
+    if (debug_nonfinite() && !(std::isfinite(r.x) && std::isfinite(r.y) && std::isfinite(r.z)))  // diagnostic hook (orc_set_debug_nonfinite): WHERE a non-finite sample is born
+      std::fprintf(stderr, "orc nonfinite li: material %d f (%g %g %g) pdf %g light_pdf %g d %g |n_L.wi| %g n.wi %g n.wo %g\n", (int)out.material[to], f.x, f.y, f.z, pdf, st.pdf[to], d,
+                   std::fabs(light_n.dot(-wi)), out.n[to].dot(wi), out.n[to].dot(wo));
+    return r;
   }
 
   static float luminance(const V3& c) {  // color::y, utils/color.hpp:13-16
@@ -357,6 +361,10 @@ struct tile_renderer_t {
     if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) return false;
     const float weight = n.dot(sampled);
     st.beta[index] = beta * (f * (std::fabs(weight) / pdf));
+    if (debug_nonfinite() && std::isfinite(beta.x) && std::isfinite(beta.y) && std::isfinite(beta.z) &&
+        !(std::isfinite(st.beta[index].x) && std::isfinite(st.beta[index].y) && std::isfinite(st.beta[index].z)))
+      std::fprintf(stderr, "orc nonfinite beta: material %d depth %u f (%g %g %g) pdf %g n.sampled %g n.wo %g beta (%g %g %g)\n", (int)out.material[from], st.depth[index], f.x, f.y, f.z, pdf, weight,
+                   n.dot(wi), beta.x, beta.y, beta.z);
     const float off = (weight < 0.0f) ? -0.0001f : 0.0001f;  // offset(), math/vector.hpp:14-21
     const V3 np = p + n * off;
     rays.px[to] = np.x; rays.py[to] = np.y; rays.pz[to] = np.z;
@@ -461,6 +469,8 @@ extern "C" {
 void orc_set_scalar(int on) { scalar_default() = on; }
 // 0 (default): equal-distance ties as in the reference (first met wins); 1: lowest primitive index wins, as on the device
 void orc_set_tie_rule(int lowest_prim) { tie_default() = lowest_prim; }
+// diagnostic: 1 = print to stderr where a non-finite value enters a path (li() or the throughput update); results are unchanged
+void orc_set_debug_nonfinite(int on) { debug_nonfinite() = on; }
 
 void* orc_create(const phx_scene* scene, const phx_options* options) {
   oracle_t* o = new oracle_t();

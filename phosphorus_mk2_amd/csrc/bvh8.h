@@ -168,17 +168,9 @@ PHX_HD uint32_t perm_xor8(uint32_t x, uint32_t oct) {
 
 // The 8 box tests of one node for one ray: bit i of the result = child slot i may be hit.
 // Conservative: the exit distance is scaled by (1 + 2^-20) before the comparison with the entry distance (8 ulp between
-// them; tn >= 0, and a negative exit distance is a miss either way), IEEE maxNum/minNum.  PHX_PACKED_FMA: the near/far
-// planes of an axis through one packed FMA (v_pk_fma_f32) — measured 1 % slower than plain FMAs here.
-#ifndef PHX_PACKED_FMA
-#define PHX_PACKED_FMA 0  /* measured: plain v_fma_f32 0.8-1.2 % faster than v_pk_fma_f32 here (a packed op takes two issue slots and needs its operands in register pairs) */
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && PHX_PACKED_FMA
-#define PHX_USE_PK 1
-typedef float phx_f2 __attribute__((ext_vector_type(2)));
-#else
-#define PHX_USE_PK 0
-#endif
+// them; tn >= 0, and a negative exit distance is a miss either way), IEEE maxNum/minNum.  (Two measured-and-rejected encodings of
+// the same test — v_pk_fma_f32 plane pairs, fp16 planes through v_perm_b32 + v_fma_mix_f32 — are kept as
+// profiles/r06_bvh8_rejected_encodings.patch, not here.)
 #ifndef PHX_SIGN_ACCUM
 #define PHX_SIGN_ACCUM 1
 #endif
@@ -191,9 +183,6 @@ typedef float phx_f2 __attribute__((ext_vector_type(2)));
 #ifndef PHX_BITOP3
 #define PHX_BITOP3 1
 #endif
-#ifndef PHX_F16_PLANES
-#define PHX_F16_PLANES 0  /* experiment, measured 4 % SLOWER (below) */
-#endif
 PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px, float py, float pz, const RayCtx& r, float tmax) {
   const uint32_t e = w[2];
   const float sx = u32_as_f32((e & 0xffu) << 23), sy = u32_as_f32(((e >> 8) & 0xffu) << 23), sz = u32_as_f32(((e >> 16) & 0xffu) << 23);
@@ -203,39 +192,7 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
   const float pad_far = 1.00000095367431640625f;  // 1 + 2^-20
   // words: 4,5 qlox | 6,7 qloy | 8,9 qloz | 10,11 qhix | 12,13 qhiy | 14,15 qhiz
   uint32_t hit8 = 0;
-#if defined(__HIP_DEVICE_COMPILE__) && PHX_F16_PLANES
-  // Experiment: instead of 48 v_cvt_f32_ubyteN per visit, ONE v_perm_b32 turns two plane bytes into two fp16 numbers 1024 + q
-  // (0x6400 | q: exact, the ulp of fp16 at 1024 is 1) and the plane distance is v_fma_mix_f32(half, a, b - 1024 a), the fp16
-  // operand widened inside the FMA (b - 1024 a is rounded once more than b: at most 2^-14 grid units of plane position, far
-  // inside the 10^-3 grid units of slack the boxes carry).  17 VALU instructions fewer per visit, results identical (the parity
-  // suite passes) — and 4 % slower (73.1 vs 70.4 ms per frame at 100 k, 91.9 vs 89.1 at 1 M): v_fma_mix_f32 / v_perm_b32 do not
-  // issue at the rate of v_fma_f32 / v_cvt_f32_ubyte.  Kept for the record, off.
-  typedef _Float16 phx_h2 __attribute__((ext_vector_type(2)));
-  const float bx1 = fmaf(-1024.0f, ax, bx), by1 = fmaf(-1024.0f, ay, by), bz1 = fmaf(-1024.0f, az, bz);
-  const uint32_t k64 = 0x64646464u;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const uint32_t nearx = nx ? w[10 + half] : w[4 + half], farx = nx ? w[4 + half] : w[10 + half];
-    const uint32_t neary = ny ? w[12 + half] : w[6 + half], fary = ny ? w[6 + half] : w[12 + half];
-    const uint32_t nearz = nz ? w[14 + half] : w[8 + half], farz = nz ? w[8 + half] : w[14 + half];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      // v_perm_b32(S0, S1, sel): result byte i = byte sel[i] of {S0 (4..7), S1 (0..3)} -> (q[2p], 0x64, q[2p+1], 0x64)
-      const uint32_t sel = p == 0 ? 0x00050004u : 0x00070006u;
-      const phx_h2 hnx = __builtin_bit_cast(phx_h2, __builtin_amdgcn_perm(nearx, k64, sel)), hfx = __builtin_bit_cast(phx_h2, __builtin_amdgcn_perm(farx, k64, sel));
-      const phx_h2 hny = __builtin_bit_cast(phx_h2, __builtin_amdgcn_perm(neary, k64, sel)), hfy = __builtin_bit_cast(phx_h2, __builtin_amdgcn_perm(fary, k64, sel));
-      const phx_h2 hnz = __builtin_bit_cast(phx_h2, __builtin_amdgcn_perm(nearz, k64, sel)), hfz = __builtin_bit_cast(phx_h2, __builtin_amdgcn_perm(farz, k64, sel));
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float tnx = fmaf((float)hnx[q], ax, bx1), tny = fmaf((float)hny[q], ay, by1), tnz = fmaf((float)hnz[q], az, bz1);
-        const float tfx = fmaf((float)hfx[q], ax, bx1), tfy = fmaf((float)hfy[q], ay, by1), tfz = fmaf((float)hfz[q], az, bz1);
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)) * pad_far;
-        if (tn <= tf) hit8 |= 1u << (4 * half + 2 * p + q);  // empty slots have inverted boxes (qlo 255 > qhi 0)
-      }
-    }
-  }
-#elif defined(__HIP_DEVICE_COMPILE__) && PHX_SIGN_ACCUM
+#if defined(__HIP_DEVICE_COMPILE__) && PHX_SIGN_ACCUM
   // Same test, cheaper instructions (scripts/micro/valu_ops.hip: v_mul/v_add/v_sub issue in 2 clocks, v_max/v_min/v_cmp/
   // v_cndmask/v_cvt in 4): the clamps against 0 and tmax become two subtractions, "miss" is the sign bit of
   // (tf - tn) | (tmax - tn) | tf, and a funnel shift collects it — no compare, no select.  Children run 7..0 so that child j
@@ -286,9 +243,6 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
 #undef bz
 #endif
 #else
-#if PHX_USE_PK
-  const phx_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
-#endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const uint32_t nearx = nx ? w[10 + half] : w[4 + half], farx = nx ? w[4 + half] : w[10 + half];
@@ -297,16 +251,6 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sh = 8 * j;
-#if PHX_USE_PK
-      const phx_f2 qx = {(float)((nearx >> sh) & 0xffu), (float)((farx >> sh) & 0xffu)};
-      const phx_f2 qy = {(float)((neary >> sh) & 0xffu), (float)((fary >> sh) & 0xffu)};
-      const phx_f2 qz = {(float)((nearz >> sh) & 0xffu), (float)((farz >> sh) & 0xffu)};
-      const phx_f2 tx = __builtin_elementwise_fma(qx, ax2, bx2);
-      const phx_f2 ty = __builtin_elementwise_fma(qy, ay2, by2);
-      const phx_f2 tz = __builtin_elementwise_fma(qz, az2, bz2);
-      const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f)), tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax)) * pad_far;
-      if (tn <= tf) hit8 |= 1u << (4 * half + j);  // empty slots have inverted boxes (qlo 255 > qhi 0)
-#else
       const float tnx = fmaf((float)((nearx >> sh) & 0xffu), ax, bx);
       const float tny = fmaf((float)((neary >> sh) & 0xffu), ay, by);
       const float tnz = fmaf((float)((nearz >> sh) & 0xffu), az, bz);
@@ -315,8 +259,7 @@ PHX_HD uint32_t node_hit8(const uint32_t* w /* 16 words of the node */, float px
       const float tfz = fmaf((float)((farz >> sh) & 0xffu), az, bz);
       const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
       const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)) * pad_far;
-      if (tn <= tf) hit8 |= 1u << (4 * half + j);
-#endif
+      if (tn <= tf) hit8 |= 1u << (4 * half + j);  // empty slots have inverted boxes (qlo 255 > qhi 0)
     }
   }
 #endif

@@ -11,6 +11,19 @@
 #include <future>
 #include <thread>
 
+// Study knobs of the builder (tree shape experiments: scripts/width_study.py, scripts/cnode_probe.sh) are read from the environment ONLY in
+// builds made with -DPHX_STUDY_KNOBS=1 (tests/native/libhost_bvh8.so, `make variant NAME=study EXTRA=-DPHX_STUDY_KNOBS=1`): the product
+// library reads none of them, so a stray variable cannot change its trees.
+#ifndef PHX_STUDY_KNOBS
+#define PHX_STUDY_KNOBS 0
+#endif
+static inline const char* study_knob(const char* name) {
+#if PHX_STUDY_KNOBS
+  return getenv(name);
+#else
+  (void)name; return nullptr;
+#endif
+}
 namespace phx {
 namespace {
 
@@ -193,7 +206,7 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
   B.next = 1;
   B.spare_threads = std::max(0, num_threads - 1);
   std::vector<uint64_t> codes;
-  if (getenv("PHX_HOST_LBVH") && atoi(getenv("PHX_HOST_LBVH"))) {  // experiment: the device builder's binary tree, on the host
+  if (study_knob("PHX_HOST_LBVH") && atoi(study_knob("PHX_HOST_LBVH"))) {  // experiment: the device builder's binary tree, on the host
     Box cbox; cbox.reset();
     for (uint32_t i = 0; i < n; ++i) cbox.grow(cen.data() + 3 * (size_t)i);
     auto spread = [](uint64_t v) { uint64_t r = 0; for (int b = 0; b < 21; ++b) r |= ((v >> b) & 1ull) << (3 * b); return r; };
@@ -227,7 +240,7 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
   // 82.7, 1 M 98.3 -> 93.6, 3 M 109.2 -> 100.1, 10 M 250.9 -> 246.0.  Mode 2 below optimises on the boxes the traversal really
   // tests and wins or ties everywhere (greedy / mode 1 / mode 2: 100 k 67.8 / 70.9 / 67.0 ms, 300 k 84.3 / 76.4 / 76.6, 1 M 95.6 /
   // 89.7 / 87.5): it is the default.  PHX_COLLAPSE=0 / 1 / 2 forces greedy / optimal on true boxes / optimal on quantised boxes.
-  static const int collapse_env = getenv("PHX_COLLAPSE") ? atoi(getenv("PHX_COLLAPSE")) : -1;
+  static const int collapse_env = study_knob("PHX_COLLAPSE") ? atoi(study_knob("PHX_COLLAPSE")) : -1;
   const int collapse_mode = collapse_env < 0 ? 2 : collapse_env;
   const bool use_dp = collapse_mode == 1;
   const float C_NODE = 2.4f, C_TRI = 1.0f;  // with one triangle per leaf slot only the sum of the nodes' areas is left to minimise
@@ -266,14 +279,14 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     const uint32_t nn = B.next.load();
     std::vector<float> sub(nn, 0.0f);
     cuts.resize(nn);
-    const float CN = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f, CT = 1.0f;  // measured VALU time per node visit : per triangle test
+    const float CN = study_knob("PHX_CNODE") ? (float)atof(study_knob("PHX_CNODE")) : 1.6f, CT = 1.0f;  // measured VALU time per node visit : per triangle test
     // experiment knob (16 = cuts within 4 levels), clamped: the DP tables below hold 256 heap positions and a position h < limit
     // looks at its children 2h and 2h+1
-    static const uint32_t dp_heap_limit = (uint32_t)std::min(128, std::max(2, getenv("PHX_DP_HEAP") ? atoi(getenv("PHX_DP_HEAP")) : 128));
+    static const uint32_t dp_heap_limit = (uint32_t)std::min(128, std::max(2, study_knob("PHX_DP_HEAP") ? atoi(study_knob("PHX_DP_HEAP")) : 128));
     // study knob (scripts/width_study.py, read per build): at most this many children per node — 4 gives the tree a 4-wide collapse of the
     // same binary tree would have, in the same 64-byte nodelets (half of their slots empty): node visits and triangle tests of a
     // narrower layout can be counted with the unchanged traversal
-    const int width = std::min(8, std::max(2, getenv("PHX_WIDTH") ? atoi(getenv("PHX_WIDTH")) : 8));
+    const int width = std::min(8, std::max(2, study_knob("PHX_WIDTH") ? atoi(study_knob("PHX_WIDTH")) : 8));
     struct Local {
       float best[256][9]; uint8_t split[256][9]; uint8_t done[256][9]; uint32_t node[256];
     };

@@ -24,6 +24,16 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#ifndef PHX_STUDY_KNOBS
+#define PHX_STUDY_KNOBS 0  /* 1: the builder's study knobs (PHX_LBVH_COLLAPSE, PHX_CNODE) are read from the environment; the product library reads none (bvh_build.cpp) */
+#endif
+static inline const char* gpu_study_knob(const char* name) {
+#if PHX_STUDY_KNOBS
+  return getenv(name);
+#else
+  (void)name; return nullptr;
+#endif
+}
 namespace phx {
 namespace {
 
@@ -533,12 +543,12 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   Tree2 T{left, right, first, last, nbox, sorted, (int)n};
   // optimal collapse (PHX_LBVH_COLLAPSE=0: the greedy surface-area expansion)
   uint32_t* cut = nullptr; uint8_t* cut_count = nullptr; float* sub = nullptr;
-  if (!(getenv("PHX_LBVH_COLLAPSE") && atoi(getenv("PHX_LBVH_COLLAPSE")) == 0)) {
+  if (!(gpu_study_knob("PHX_LBVH_COLLAPSE") && atoi(gpu_study_knob("PHX_LBVH_COLLAPSE")) == 0)) {
     sub = (float*)dalloc(4 * (size_t)n);
     cut = (uint32_t*)dalloc(4 * 8 * (size_t)n); cut_count = (uint8_t*)dalloc((size_t)n);
     if (!sub || !cut || !cut_count) { std::snprintf(err, errlen, "hipMalloc failed (collapse tables)"); cleanup(); return BVH_GPU_RECOVERABLE; }
     HCHK(hipMemsetAsync(flags, 0, 4 * (size_t)n, stream));  // k_fit is done with its arrival flags
-    const float cn = getenv("PHX_CNODE") ? (float)atof(getenv("PHX_CNODE")) : 1.6f;
+    const float cn = gpu_study_knob("PHX_CNODE") ? (float)atof(gpu_study_knob("PHX_CNODE")) : 1.6f;
     hipLaunchKernelGGL(k_collapse_dp, dim3((n + 64 * DP_WAVES - 1) / (64 * DP_WAVES)), dim3(64 * DP_WAVES), 0, stream, (int)n, left, right, parent, nbox, flags, sub, cut, cut_count, cn, 1.0f);
     HCHK(hipGetLastError());
   }

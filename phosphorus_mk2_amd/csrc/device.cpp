@@ -803,7 +803,7 @@ int phx_device::run_frame() {
   for (int k = 0; k < 8; ++k) stats.stack_pushes[k] = ds.stack_pushes[k];
   stats.primary_packets = ds.primary_packets; stats.primary_fallbacks = ds.primary_fallbacks; stats.primary_node_tests = ds.primary_node_tests;
   stats.primary_tri_tests = ds.primary_tri_tests; stats.primary_tri_lanes_hit = ds.primary_tri_lanes_hit;
-  if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace: " + std::to_string(ds.watchdog) + " wave(s) hit the iteration watchdog: the frame is incomplete");
+  if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace / k_shade_g: " + std::to_string(ds.watchdog) + " wave(s) hit a watchdog (traversal iterations, or a wait on the shade kernel's append ring): the frame is incomplete");
   stats.trace_ms = stats.closest_ms + stats.shadow_ms + stats.primary_ms;
   stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   static const bool host_timing = std::getenv("PHX_HOST_TIMING") != nullptr;
@@ -833,8 +833,9 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   auto pick_samples = [&]() -> uint32_t {
     if (opt.samples_in_flight) return opt.samples_in_flight;
     const uint64_t budget = std::max<uint64_t>(path_budget(path_bytes), P);
-    // (1/16 of slack: the batch that run_frame sized for all of its samples overshoots its pixel cap by up to one tile)
-    const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((budget + budget / 16) / P, 0x7ffffff0ull / P));
+    // (no slack: run_frame never hands over a batch above its pixel cap = budget / samples of a pass, so P x spp <= budget holds for every
+    // batch it sized; a caller's own tile list — or the cap's floor of 64 k pixels — may exceed it, and then the spp range is split)
+    const uint32_t smax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / P, 0x7ffffff0ull / P));
     const uint32_t npasses = (spp + smax - 1) / smax;
     return (spp + npasses - 1) / npasses;
   };
@@ -843,7 +844,6 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   // object already holds are large enough: a batch that has to GROW them asks the device again — another device object, torch films or
   // RCCL buffers may have taken memory since the reading was made.
   if ((size_t)P * S > hit.n && !opt.samples_in_flight) { budget_bytes = 0; S = std::min(pick_samples(), spp); }
-  S = std::min(S, spp);
   if ((size_t)P * S >= 0x7fffffffull) return fail(PHX_ERR_ARG, "too many paths in flight");
 
   // pixel table of the batch; a frame loop presents the same tiles again and again, so the upload is skipped when nothing changed

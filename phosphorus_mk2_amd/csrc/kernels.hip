@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 namespace phx {
@@ -25,6 +26,12 @@ namespace phx {
 #endif
 #ifndef PHX_COUNT
 #define PHX_COUNT 0  /* 1: instrumented build that counts node visits and triangle tests (bench.py's device-layout byte model) */
+#endif
+#ifndef PHX_SHADE_TIMING
+#define PHX_SHADE_TIMING 0  /* probe builds only: s_memtime around k_shade_g's sort phase and shading rounds, summed into DevStats fields the count build uses (block_append2 below tests it too) */
+#endif
+#ifndef PHX_SHADE_PREFETCH
+#define PHX_SHADE_PREFETCH 2  /* k_shade_g: 1 = hit record and ray of the next round are requested before this round's append; 2 = and path state + triangle record right after it (35.9 / 35.3 / 34.8 ms for 0 / 1 / 2: profiles/r05_c_shade_prefetch_ab.log) */
 #endif
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
@@ -66,6 +73,7 @@ __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, 
 #endif
     cnt[nwaves] = total ? atomicAdd(wave == 0 ? counter_a : counter_b, total) : 0u;
 #if PHX_SHADE_TIMING
+    static_assert(offsetof(DevStats, tri_pending_lane_iters) == offsetof(DevStats, idle_lane_iters) + sizeof(unsigned long long), "probe[0] / probe[1] are DevStats::idle_lane_iters / tri_pending_lane_iters");
     if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); atomicAdd(&probe[0], (unsigned long long)(clock64() - ta_)); atomicAdd(&probe[1], 1ull); }
 #endif
   }
@@ -927,9 +935,6 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #ifndef PHX_SHADE_KEY_PROBE
 #define PHX_SHADE_KEY_PROBE 0
 #endif
-#ifndef PHX_SHADE_TIMING
-#define PHX_SHADE_TIMING 0  /* probe builds only: s_memtime around k_shade_g's sort phase and shading rounds, summed into DevStats fields the count build uses */
-#endif
 // probe builds (-DPHX_SHADE_TIMING=1, scripts/shade_phase_probe.py): s_memtime at the phase boundaries of a shading round, per wave.
 // PHX_PHASE(n) closes phase n: everything the wave has in flight is waited for first, so that a phase is charged the latency of what it
 // asked for (loads issued in a phase and consumed later would otherwise be billed to the consumer).
@@ -939,9 +944,6 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #else
 #define PHX_PHASE_DECL
 #define PHX_PHASE(n)
-#endif
-#ifndef PHX_SHADE_PREFETCH
-#define PHX_SHADE_PREFETCH 2  /* k_shade_g: 1 = hit record and ray of the next round are requested before this round's append; 2 = and path state + triangle record right after it (35.9 / 35.3 / 34.8 ms for 0 / 1 / 2: profiles/r05_c_shade_prefetch_ab.log) */
 #endif
 #ifndef PHX_SCALAR_F
 #define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
@@ -963,11 +965,111 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
     if (mine_) { ConstMat& cm = *((ConstMat*)(sc.materials) + m0_); body; }                                                    \
     todo_ &= ~__ballot(mine_);                                                                                                \
   }
+// ---- k_shade_g's append: a workgroup-local ring in LDS, no barrier and no global atomic inside a shading round -------------------------
+// Until round 5 every round of 512 entries ended in block_append2: barrier, the workgroup's two atomics on the queue counters, barrier —
+// 24 % of a wave's time (profiles/r05_c_shade_phases.md: the atomics' round trip ~2 200 clocks, ~5 000 waiting for the slowest of the eight
+// waves, every round).  Now a WAVE reserves its slots in a ring of 2 x PHX_RING_BLK entries with one ds_add_rtn, writes its records there and
+// adds its count to the block's commit counter; the wave whose commit completes a block of PHX_RING_BLK entries flushes it: ONE global
+// atomic for exactly PHX_RING_BLK slots and coalesced 16-byte stores.  A block is written again only after its flush (`flushed`, per
+// buffer), which the writers of the block after next wait for — they wait for waves with LOWER ring positions only, so there is no cycle —
+// and what is left in the ring when the workgroup has shaded its last window goes out with an exact count.  The queues stay dense; their
+// ORDER changes (blocks of 256 in completion order), which no result depends on (one closest-hit ray and at most one shadow ray per path
+// and step; the film add is per path).  LDS: 16 KB (survivors, 32 B) + 24 KB (NEE rays, 48 B) per workgroup, two workgroups per CU.
+// Ordering: the LDS executes the DS instructions of one wave in issue order, so "records, then commit" and "reads, then release" need no
+// fence in hardware; s_waitcnt lgkmcnt(0) + a compiler barrier keep the compiler (and any doubt) out.  NOT __builtin_amdgcn_fence: a
+// workgroup-scope fence also waits for the wave's global loads — the next round's records, requested right before the append.
+#ifndef PHX_SHADE_RING
+#define PHX_SHADE_RING 1
+#endif
+#ifndef PHX_RING_BLK
+#define PHX_RING_BLK 256u  /* entries per flush = per global atomic (the counters sustain ~80 returning atomics per us and address: 256 keeps the kernel near 50) */
+#endif
+#ifndef PHX_RING_SPINS
+#define PHX_RING_SPINS (1u << 19)
+#endif
+struct RingCtl { uint32_t head, committed[2], flushed[2], dead; };  // dead: a wait of this workgroup timed out — its later appends are dropped, the frame fails
+#define PHX_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int NREC>
+__device__ __forceinline__ void ring_flush(const float4* ring /* [NREC][2 x BLK] */, uint32_t first, uint32_t n, uint32_t* gcounter, float4* g0, float4* g1, float4* g2) {
+  const uint32_t lane = __lane_id();
+  uint32_t gb = 0;
+  if (lane == 0) gb = atomicAdd(gcounter, n);
+  gb = PHX_UNI(gb);
+  for (uint32_t k = lane; k < n; k += 64u) {
+    g0[gb + k] = ring[first + k];
+    g1[gb + k] = ring[2u * PHX_RING_BLK + first + k];
+    if (NREC == 3) g2[gb + k] = ring[4u * PHX_RING_BLK + first + k];
+  }
+}
+template <int NREC>
+__device__ __forceinline__ void ring_append(bool want, const float4& r0, const float4& r1, const float4& r2, RingCtl* ctl, float4* ring,
+                                            uint32_t* gcounter, float4* g0, float4* g1, float4* g2, unsigned long long* watchdog) {
+  constexpr uint32_t BLK = PHX_RING_BLK;
+  static_assert((BLK & (BLK - 1u)) == 0u && BLK >= 64u, "a wave's reservation spans at most two blocks");
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return;  // wave-uniform
+  const uint32_t lane = __lane_id(), n = (uint32_t)__popcll(mask);
+  uint32_t pos = 0;
+  if (lane == 0) pos = __hip_atomic_fetch_add(&ctl->head, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  pos = PHX_UNI(pos);
+  const uint32_t gen0 = pos / BLK, gen1 = (pos + n - 1u) / BLK;  // generation g lives in buffer g & 1; it is that buffer's (g >> 1)-th use
+  // (a wait is rare: the block after next fills a whole round later than this one's flush starts.  Every wait is bounded — PHX_RING_SPINS
+  // sleeps of 64 clocks, ~30 ms — after which the wave counts itself in DevStats::watchdog and goes on: the frame is then reported as failed
+  // (device.cpp), exactly as for k_trace's watchdog; no wave can spin for ever.)
+  uint32_t spins = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t gen = h ? gen1 : gen0;
+    if (h && gen1 == gen0) break;
+    while (PHX_UNI(__hip_atomic_load(&ctl->flushed[gen & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (gen >> 1)) {
+      if (++spins > PHX_RING_SPINS || PHX_UNI(__hip_atomic_load(&ctl->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+        if (lane == 0) { atomicAdd(watchdog, 1ull); __hip_atomic_store(&ctl->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  asm volatile("" ::: "memory");
+  if (want) {
+    const uint32_t idx = (pos + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & (2u * BLK - 1u);
+    ring[idx] = r0; ring[2u * BLK + idx] = r1;
+    if (NREC == 3) ring[4u * BLK + idx] = r2;
+  }
+  PHX_LDS_ORDER();  // the records are in LDS before the commit
+  const uint32_t n0 = min(n, (gen0 + 1u) * BLK - pos), n1 = n - n0;
+  uint32_t c0 = 0, c1 = 0;
+  if (lane == 0) {
+    c0 = __hip_atomic_fetch_add(&ctl->committed[gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n1) c1 = __hip_atomic_fetch_add(&ctl->committed[gen1 & 1u], n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  c0 = PHX_UNI(c0); c1 = PHX_UNI(c1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t gen = h ? gen1 : gen0;
+    if (h ? (n1 != 0u && c1 + n1 == BLK) : (c0 + n0 == BLK)) {  // this wave's commit completed the block: it flushes it
+      asm volatile("" ::: "memory");
+      ring_flush<NREC>(ring, (gen & 1u) * BLK, BLK, gcounter, g0, g1, g2);
+      PHX_LDS_ORDER();  // the block has been read before it is handed back
+      if (lane == 0) {
+        __hip_atomic_store(&ctl->committed[gen & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PHX_LDS_ORDER();
+        __hip_atomic_fetch_add(&ctl->flushed[gen & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+}
 template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
   static_assert(WINDOW <= 65536 && BLOCK >= NB + 2 && NB == 64, "perm holds 16-bit positions; one wave scans the NB material buckets");
+#if PHX_SHADE_RING
+  __shared__ float4 ring_a[2 * 2 * PHX_RING_BLK];  // survivors: (o, path | SPECULAR << 31), (d, tmax)
+  __shared__ float4 ring_b[3 * 2 * PHX_RING_BLK];  // NEE rays: (o, path), (d, tmax), (beta * Li)
+  __shared__ RingCtl ring_ctl[2];
+  if (threadIdx.x < sizeof(ring_ctl) / 4u) reinterpret_cast<uint32_t*>(ring_ctl)[threadIdx.x] = 0u;  // visible after the first barrier every thread reaches
+#else
   __shared__ uint32_t lds_sr[2 * ((BLOCK >> 6) + 1)];
+#endif
   __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
   __shared__ uint16_t perm[WINDOW];
   const uint32_t count = pb.counters[q * CNT_STRIDE];
@@ -1217,7 +1319,18 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
         PHX_PHASE(3)  // roulette, bsdf_sample, path state store
-        if constexpr (STAGE1) request_round(k + 1);  // in flight across the append's barriers and atomics (the barriers wait for LDS traffic only)
+        if constexpr (STAGE1) request_round(k + 1);  // in flight across the append (the append waits for LDS traffic only)
+#if PHX_SHADE_RING
+        {
+          const v3 nxt_o = p + n * off;
+          ring_append<3>(want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
+                         &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->watchdog);
+          ring_append<2>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+                         &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr, &pb.stats->watchdog);
+        }
+        PHX_PHASE(4)  // the append: slot reservation, records to LDS, commit; for one wave in BLK / 64 rounds the flush of a block
+        if constexpr (STAGE2) request_round_dependents();
+#else
         uint32_t no, ns;
         #if PHX_SHADE_TIMING
         block_append2<BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_sr, no, ns, &pb.stats->idle_lane_iters);
@@ -1236,6 +1349,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
           pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
         }
+#endif
         PHX_PHASE(5)  // the stores of the two queue entries (waited for: the probe charges them here, the product build does not wait)
 #if PHX_SHADE_TIMING
         ++ph_rounds;
@@ -1244,6 +1358,19 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     }
     __syncthreads();  // perm and bucket are rewritten by the next window
   }
+#if PHX_SHADE_RING
+  // what the workgroup's last windows left in the rings: every complete block has been flushed by the wave that completed it (before that
+  // wave reached the barrier above); the open block goes out with its exact count, the survivors' by wave 0, the NEE rays' by wave 1
+  __syncthreads();
+  if (threadIdx.x < 128u) {
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t head = ring_ctl[w].head, left = head & (PHX_RING_BLK - 1u), first = ((head / PHX_RING_BLK) & 1u) * PHX_RING_BLK;
+    if (left) {
+      if (w == 0u) ring_flush<2>(ring_a, first, left, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr);
+      else ring_flush<3>(ring_b, first, left, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc);
+    }
+  }
+#endif
 #if PHX_SHADE_TIMING
   if ((threadIdx.x & 63u) == 0u) {  // probe build only: s_memtime ticks per phase, summed over the waves (DevStats fields of the count build)
     for (int k = 0; k < 6; ++k) atomicAdd(&pb.stats->stack_pushes[k], ph_acc[k]);

@@ -346,17 +346,19 @@ def multi_material_soup(n, seed=1234, width=1280, height=720):
     return s
 
 
-def showroom(n, seed=5, width=1280, height=720, materials=None):
+def showroom(n, seed=5, width=1280, height=720, materials=None, closed=False):
     """A non-uniform, mesh-like scene (connected surfaces, three orders of magnitude of triangle sizes): a closed grey room with a
     ceiling light holding 24 lat/long-tessellated spheres of radius 0.04..0.55 whose triangle counts are NOT proportional to their
     area (the smallest sphere gets as many triangles as the largest: "teapot in a stadium"), about n triangles in total.  Used to
     check both tree builders — and PHX_BVH_AUTO's choice between them — on something that is not the uniform soup of SURVEY §8(d).
-    With `materials` the spheres cycle through that list (material 0 stays the room's)."""
+    With `materials` the spheres cycle through that list (material 0 stays the room's).  The room is open towards the camera (which stands
+    in front of it, at the origin); `closed` pulls floor, ceiling and side walls past the camera and adds the wall behind it: no path
+    leaves the room, every path ends by roulette, the depth limit or absorption."""
     rng = np.random.default_rng(seed)
     mats = [diffuse(0.73, 0.73, 0.73)] + (list(materials) if materials else [diffuse(0.6, 0.3, 0.2), diffuse(0.2, 0.5, 0.7)])
     nm = len(mats)
     mats.append(emitter(*LE))
-    X0, X1, Y0, Y1, Z0, Z1 = -2.0, 2.0, -1.0, 1.6, -4.6, -0.4
+    X0, X1, Y0, Y1, Z0, Z1 = -2.0, 2.0, -1.0, 1.6, -4.6, (0.4 if closed else -0.4)
     meshes = [
         _quad((X0, Y0, Z1), (X1, Y0, Z1), (X1, Y0, Z0), (X0, Y0, Z0), 0),   # floor
         _quad((X0, Y0, Z0), (X1, Y0, Z0), (X1, Y1, Z0), (X0, Y1, Z0), 0),   # back
@@ -365,6 +367,8 @@ def showroom(n, seed=5, width=1280, height=720, materials=None):
         _quad((X0, Y1, Z0), (X1, Y1, Z0), (X1, Y1, Z1), (X0, Y1, Z1), 0),   # ceiling
         _quad((-0.8, Y1 - 0.01, -1.7), (-0.8, Y1 - 0.01, -3.3), (0.8, Y1 - 0.01, -3.3), (0.8, Y1 - 0.01, -1.7), nm),
     ]
+    if closed:
+        meshes.append(_quad((X1, Y0, Z1), (X0, Y0, Z1), (X0, Y1, Z1), (X1, Y1, Z1), 0))   # the wall behind the camera, facing the room
     nspheres = 24
     per = max(8, int(n) // nspheres)
     for k in range(nspheres):
@@ -381,4 +385,19 @@ def showroom(n, seed=5, width=1280, height=720, materials=None):
         c = ((i + 1) * segs + j).ravel(); d = ((i + 1) * segs + (j + 1) % segs).ravel()
         f = np.concatenate([np.stack([a, b, d], 1), np.stack([a, d, c], 1)]).astype(np.uint32)  # outward-facing; the pole rows hold slivers of zero area
         meshes.append(MeshDesc(vertices=v, faces=f, sets=[(1 + k % (nm - 1), np.arange(len(f), dtype=np.uint32))]))
-    return SceneDesc(meshes, mats, CameraDesc(width, height, 1.9), name=f"showroom{n}")
+    return SceneDesc(meshes, mats, CameraDesc(width, height, 1.9), name=f"showroom{n}{'_closed' if closed else ''}")
+
+
+def showroom_materials():
+    """the 16 closure recipes of the BMW stand-in (closure_zoo() + four diffuse tints) plus Blender's glass node twice — sharp
+    (IoR 1.45) and frosted (IoR 1.33, roughness 0.2) — whose closure weights depend on the hit (k_shade_g<PERHIT>): 18 materials"""
+    return closure_zoo() + [diffuse(0.7, 0.2, 0.2), diffuse(0.2, 0.7, 0.2), diffuse(0.2, 0.2, 0.7), diffuse(0.5, 0.5, 0.1),
+                            glass(1.45, 0.0, (0.95, 0.98, 0.95), (1.0, 1.0, 1.0)), glass(1.33, 0.2, (0.9, 0.9, 1.0), (0.9, 0.9, 0.9))]
+
+
+def bmw_showroom(n=500_000, width=1920, height=1080):
+    """The mesh-geometry stand-in for BASELINE configs 3 / 5: the CLOSED showroom — connected surfaces, triangle sizes
+    over three decades, no path escapes — with showroom_materials() on its 24 spheres.  multi_material_soup() stays the open, uniform one."""
+    s = showroom(n, width=width, height=height, materials=showroom_materials(), closed=True)
+    s.name = f"bmw_showroom{n}"
+    return s

@@ -308,9 +308,11 @@ class HipDevice:
         return pool.reshape(-1, 16), grid[:3].copy(), grid[3:].copy()
 
     def close(self):
+        """~xpu_t: joins a frame that is still running (its callbacks may fire until then: they are kept alive up to here)"""
         if self._h:
             self._lib.phx_dev_destroy(self._h)
             self._h = None
+        self._keep = None
 
     def __del__(self):
         try:

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Run ON the GPU box: the node-cost constant of the device builder's optimal collapse (PHX_CNODE; triangle cost = 1)
+# (the knob exists in a study build only: make -C phosphorus_mk2_amd/csrc variant NAME=study EXTRA=-DPHX_STUDY_KNOBS=1)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+make -C $R/phosphorus_mk2_amd/csrc variant NAME=study EXTRA=-DPHX_STUDY_KNOBS=1 > /dev/null || exit 1
+export PHX_LIB=$R/phosphorus_mk2_amd/libphx_hip_study.so
 for cfg in "soup 100000" "soup 1000000" "showroom 1000000"; do
   set -- $cfg
   for cn in 1.0 1.3 1.6 2.0 2.5 3.2; do

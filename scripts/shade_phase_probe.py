@@ -4,7 +4,7 @@ latency of what it asked for); summed over waves and launches.  Prints a markdow
     python scripts/shade_phase_probe.py [width height spp]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
-os.environ["PHX_LIB"] = os.path.join(os.getcwd(), "phosphorus_mk2_amd", "libphx_hip_shtime.so")
+os.environ["PHX_LIB"] = os.environ.get("PHX_PROBE_LIB") or os.path.join(os.getcwd(), "phosphorus_mk2_amd", "libphx_hip_shtime.so")  # PHX_PROBE_LIB: another probe build (e.g. the block_append2 kernel, -DPHX_SHADE_RING=0)
 from phosphorus_mk2_amd import scenes, xpu
 W, H, SPP = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (1920, 1080, 256)))
 sc = scenes.multi_material_soup(500000, width=W, height=H)
@@ -14,7 +14,7 @@ names = ["sort of the window by material (hit record + material gather, LDS hist
          "loads landed: permuted index, hit record, ray, path state, triangle record, normals; emission added",
          "next-event estimation: light sample, bsdf_f, li",
          "roulette + bsdf_sample + path-state store",
-         "append: two barriers + the workgroup's two atomics on the queue counters",
+         "append (ring build: slot reservation in LDS, records to LDS, commit, the occasional flush of a block; -DPHX_SHADE_RING=0: two barriers + the workgroup's two atomics)",
          "stores of the next ray / shadow ray (waited for) + end-of-window barrier"]
 tot = float(sum(ph[:6]))
 print(f"k_shade_g phase probe: multi_material_soup(500 000) {W}x{H} {SPP} spp; shade kernel {st['shade_kernel_ms']:.2f} ms (probe build: every phase boundary waits for everything in flight), "

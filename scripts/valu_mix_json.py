@@ -32,6 +32,14 @@ if cc:
     rec["clock_by_kernel"] = detail
     node = [d["clock_hz"] for k, d in detail.items() if "<0>" in k or "Li0" in k]
     clock = node[0] if node else (sum(d["clock_hz"] for d in detail.values()) / len(detail) if detail else None)
+# what the micro-benchmark's loops compile to, against the node / triangle test inside k_trace (scripts/valu_mix_asm.py, asserted there)
+ac = os.path.join(out, "asm_check.json")
+if os.path.exists(ac) and open(ac).read().strip():
+    a = json.loads(open(ac).read().strip().splitlines()[-1])
+    rec["asm_check"] = {"node_test_valu_micro": a["priced_node_test_valu"], "node_test_valu_k_trace": a["ktrace_node_test"]["valu"],
+                        "node_test_cvt_ubyte_micro": a["priced_node_test_cvt_ubyte"], "node_test_cvt_ubyte_k_trace": a["ktrace_node_test"]["cvt_ubyte"],
+                        "tri_test_valu_micro": a["priced_tri_test_valu"], "tri_test_valu_k_trace": a["ktrace_tri_test"]["valu"],
+                        "skeleton_valu": a["micro_loop_skeleton"]["valu"], "skeleton_tri_valu": a["micro_loop_skeleton_tri"]["valu"]}
 rec["clock_hz"] = clock
 rec["clock_source"] = "GRBM_GUI_ACTIVE / 8 / kernel time of the node-test launches (rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -- scripts/micro/valu_mix)" if clock else None
 print(json.dumps(rec))

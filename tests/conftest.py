@@ -33,6 +33,7 @@ def host_bvh8():
     hdr = [os.path.join(ROOT, "phosphorus_mk2_amd", "csrc", h) for h in ("bvh8.h", "bvh_build.h", "phx_math.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src + hdr):
         subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-march=haswell", "-mfma", "-ffp-contract=off", "-pthread",
+                        "-DPHX_STUDY_KNOBS=1",  # the builder's study knobs (PHX_WIDTH ...) exist in this test / study library only
                         "-o", so] + src, check=True)
     lib = C.CDLL(so)
     lib.hb8_build.restype = C.c_void_p; lib.hb8_build.argtypes = [abi.f32p, C.c_uint32, C.c_int]
@@ -71,3 +72,30 @@ def bits_equal(a, b):
 def max_pixel_l2(a, b):
     d = (a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64))
     return float(np.sqrt((d * d).sum(axis=-1)).max())
+
+
+def aim_camera(scene, yaw=0.0, pitch=0.0):
+    """turn the camera `yaw` radians to the LEFT about y, then tilt it `pitch` radians UP about its x axis (CameraDesc.to_world, Imath
+    row-vector convention: the view direction (0, 0, -1) becomes (-sin yaw cos pitch, sin pitch, -cos yaw cos pitch)).  The soups'
+    identity camera (fov 1.9) sees y / |z| >= 0.75 in the bottom edge band of a 720 / 1080 / 2160-row film and |x / z| up to 1.39 in its
+    last column, while the triangle cloud ends at 0.667: every edge-band and last-column tile is black with it.  Looking
+    left and up moves the cloud to the lower right of the film, where the partial tiles are."""
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    Rx = np.array([[1, 0, 0], [0, cp, sp], [0, -sp, cp]], np.float64)
+    Ry = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]], np.float64)
+    M = np.eye(4, dtype=np.float32)
+    M[:3, :3] = (Rx @ Ry).astype(np.float32)
+    scene.camera.to_world = M
+    return scene
+
+
+def oracle_render_per_tile(O, tiles, **kw):
+    """O.render() one tile at a time -> (film with every tile filled in, [stats of each tile]): a test can then require of EACH compared tile
+    that it traced shadow rays (an all-miss tile compares black with black)"""
+    film, stats = None, []
+    for (x, y, w, h) in tiles:
+        f, st = O.render(tiles=[(x, y, w, h)], **kw)
+        film = f.copy() if film is None else film
+        film[y:y + h, x:x + w] = f[y:y + h, x:x + w]
+        stats.append(st)
+    return film, stats

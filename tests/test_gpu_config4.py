@@ -8,21 +8,26 @@ import time
 import numpy as np
 import pytest
 
-from conftest import bits_equal, random_rays
+from conftest import aim_camera, bits_equal, oracle_render_per_tile, random_rays
 
 pytestmark = pytest.mark.gpu
 
 N_TRI, W, H, SPP = 10_000_000, 3840, 2160, 4
-# tiles compared with the oracle: corners, centre, the 16-row edge band at the bottom (2160 = 67 * 32 + 16), the last column
-TILES = [(0, 0, 32, 32), (1920, 1088, 32, 32), (3808, 0, 32, 32), (640, 1600, 32, 32), (2560, 480, 32, 32),
-         (0, 2144, 32, 16), (1888, 2144, 32, 16), (3808, 2144, 32, 16)]
+# The camera looks 0.5 rad to the left and 0.3 rad up (conftest.aim_camera): the cloud then fills the lower right of the film, where the
+# partial tiles are.  (With the soups' identity camera the 16-row edge band at the bottom — 2160 = 67 * 32 + 16 — and the last column look
+# past the cloud: rounds 3-5 compared black with black there)  Tiles compared with the oracle: interior ones, the last
+# column, three of the edge band incl. the film's corner — each must trace shadow rays — and ONE declared all-miss tile, (0, 0).
+YAW, PITCH = 0.5, 0.3
+BLACK_TILE = (0, 0, 32, 32)
+TILES = [BLACK_TILE, (2880, 1088, 32, 32), (3808, 864, 32, 32), (2560, 1600, 32, 32), (3200, 480, 32, 32),
+         (1888, 2144, 32, 16), (2880, 2144, 32, 16), (3808, 2144, 32, 16)]
 
 
 @pytest.fixture(scope="module")
 def c4(orc):
     from phosphorus_mk2_amd import scenes
     t0 = time.time()
-    sc = scenes.soup(N_TRI, width=W, height=H)
+    sc = aim_camera(scenes.soup(N_TRI, width=W, height=H), YAW, PITCH)
     t1 = time.time()
     O = orc.Oracle(sc, spp=SPP)
     print(f"\n[config 4] soup {t1 - t0:.1f} s, oracle reference-layout BVH {time.time() - t1:.1f} s: {O.bvh_info()}")
@@ -30,14 +35,15 @@ def c4(orc):
     O.close()
 
 
-def _camera_rays(n, seed):
-    """rays from the camera through random film positions (the kind the frame starts with) — origin 0, looking down -z"""
+def _camera_rays(n, seed, to_world):
+    """rays from the camera through random film positions (the kind the frame starts with) — origin 0, camera space looks down -z"""
     rng = np.random.default_rng(seed)
     zoom = 1.12 * np.tan(1.9 / 2)
     x = (rng.random(n) - 0.5) * (W / H) * zoom
     y = (rng.random(n) - 0.5) * zoom
     d = np.stack([x, y, -np.ones(n)], 1)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d @ np.asarray(to_world, np.float64)[:3, :3]  # row-vector convention
     return np.zeros((n, 3), np.float32), d.astype(np.float32), np.full(n, np.finfo(np.float32).max, np.float32)
 
 
@@ -68,7 +74,7 @@ def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
 
     # (a) stage level: 16 k random rays inside the cloud + 8 k camera rays; closest hit and any hit
     o1, d1, t1 = random_rays(16384, 41)
-    o2, d2, t2 = _camera_rays(8192, 42)
+    o2, d2, t2 = _camera_rays(8192, 42, sc.camera.to_world)
     o = np.concatenate([o1, o2]); d = np.concatenate([d1, d2]); tm = np.concatenate([t1, t2])
     g = dev.trace(o, d, tm)
     orc.set_tie_rule(1)
@@ -78,7 +84,7 @@ def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
         rb = O.trace(o[:nb], d[:nb], tm[:nb], brute=True)        # linear_mbvh_kernel_t semantics: all 10 M triangles
     finally:
         orc.set_tie_rule(0)
-    assert g["hit"].mean() > 0.7
+    assert g["hit"].mean() > 0.5
     assert np.array_equal(g["prim"], r["prim"])
     assert bits_equal(g["t"], r["t"]) and bits_equal(g["u"], r["u"]) and bits_equal(g["v"], r["v"])
     assert np.array_equal(g["prim"][:nb], rb["prim"]) and bits_equal(g["t"][:nb], rb["t"])
@@ -99,51 +105,65 @@ def test_config4_trace_and_tiles_match_oracle(c4, orc, builder):
     assert fs["rays_closest"] > fs["camera_samples"] and fs["rays_shadow"] > 0
     orc.set_tie_rule(1)
     try:
-        ref, ost = O.render(rng=orc.RNG_COUNTER, seed=7, threads=16, tiles=TILES)
+        ref, osts = oracle_render_per_tile(O, TILES, rng=orc.RNG_COUNTER, seed=7, threads=1)
     finally:
         orc.set_tie_rule(0)
-    for (x, y, w, h) in TILES:
+    for (x, y, w, h), ost in zip(TILES, osts):
         assert bits_equal(film.data[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3]), (x, y)
-    assert ref[..., :3].max() > 0.0
+        if (x, y, w, h) == BLACK_TILE:  # the one tile that is MEANT to see nothing
+            assert ost["rays_closest"] == w * h * SPP and ost["rays_shadow"] == 0
+        else:  # every other compared tile hits the cloud, traces shadow rays and is lit somewhere
+            assert ost["rays_closest"] > w * h * SPP and ost["rays_shadow"] > 0, ((x, y), ost)
+            assert float(ref[y:y + h, x:x + w, :3].max()) > 0.0, (x, y)
 
 
 @pytest.mark.parametrize("width,height", [(1920, 1080), (3840, 2160)])
 def test_bmw_standin_configs_at_film_size(orc, width, height):
     """BASELINE configs #3 and #5 (the reference ships no BMW scene: the declared stand-in is a 500 k-triangle soup cycling through
     16 closure recipes, every lobe type): the general k_shade on the whole 1920x1080 / 3840x2160 film at 4 spp, ray accounting,
-    and tiles from all over the film (edge bands included) against the oracle, bit for bit."""
+    and tiles from all over the film against the oracle, bit for bit — the camera aimed so that the edge band (24 / 16 rows) and the last
+    column look INTO the cloud: every compared tile but the declared all-miss one must trace shadow rays."""
     from phosphorus_mk2_amd import scenes, xpu
     xpu.load_library()
-    sc = scenes.multi_material_soup(500_000, width=width, height=height)
+    sc = aim_camera(scenes.multi_material_soup(500_000, width=width, height=height), YAW, PITCH)
     film, st = xpu.render(sc, spp=SPP, pps=1, depth=9, seed=11, native_sink=True)
     assert st["camera_samples"] == width * height * SPP and st["tiles"] == ((width + 31) // 32) * ((height + 31) // 32)
     assert st["rays_closest"] > st["camera_samples"] and st["rays_shadow"] + st["rays_masked"] <= st["rays_closest"]
     ty = (height // 32) * 32  # the edge band: 1080 = 33 * 32 + 24, 2160 = 67 * 32 + 16
-    tiles = [(0, 0, 32, 32), (width - 32, 0, 32, 32), (width // 2, (height // 64) * 32, 32, 32), (32 * 7, 32 * 5, 32, 32),
-             (0, ty, 32, height - ty), (width - 32, ty, 32, height - ty)]
+    a32 = lambda v: (int(v) // 32) * 32
+    tiles = [BLACK_TILE, (width - 32, a32(0.4 * height), 32, 32), (a32(0.75 * width), a32(0.5 * height), 32, 32), (a32(0.6 * width), a32(0.75 * height), 32, 32),
+             (a32(0.55 * width), ty, 32, height - ty), (width - 32, ty, 32, height - ty)]
+    O = orc.Oracle(sc, spp=SPP)
     orc.set_tie_rule(1)
     try:
-        ref, _ = orc.Oracle(sc, spp=SPP).render(rng=orc.RNG_COUNTER, seed=11, threads=16, tiles=tiles)
+        ref, osts = oracle_render_per_tile(O, tiles, rng=orc.RNG_COUNTER, seed=11, threads=1)
     finally:
         orc.set_tie_rule(0)
-    for (x, y, w, h) in tiles:
+        O.close()
+    for (x, y, w, h), ost in zip(tiles, osts):
         a, b = film[y:y + h, x:x + w, :3], ref[y:y + h, x:x + w, :3]
         fin = np.isfinite(b).all(-1)
         assert np.array_equal(fin, np.isfinite(a).all(-1)) and fin.mean() > 0.99 and bits_equal(a[fin], b[fin]), (x, y)
+        if (x, y, w, h) == BLACK_TILE:
+            assert ost["rays_shadow"] == 0 and float(np.abs(b).max()) == 0.0
+        else:
+            assert ost["rays_closest"] > w * h * SPP and ost["rays_shadow"] > 0 and float(b[fin].max()) > 0.0, ((x, y), ost)
 
 
 @pytest.mark.parametrize("width,height,spp", [(1920, 1080, 1024), (3840, 2160, 4096)])
 def test_bmw_standin_configs_at_their_real_sample_counts(orc, width, height, spp):
     """BASELINE configs #3 and #5 at the sample counts BASELINE names — 1 024 and 4 096 spp: 32x32 / 64x64 jitter strata
     (src/sampling.cpp:98-112), path id = pixel * spp + sample, every sample of a pixel in ONE pass (src/xpu/cpu.cpp:160-198 runs
-    them as a loop per tile) — on two 32x32 tiles of the stand-in scene, one of them in the film's edge band (1080 = 33 * 32 + 24,
-    2160 = 67 * 32 + 16): device against oracle under BOTH tie rules.  Under the device's rule ray counts and film are exact; under
+    them as a loop per tile) — on two tiles of the stand-in scene, one of them in the film's edge band (1080 = 33 * 32 + 24,
+    2160 = 67 * 32 + 16), the camera aimed so that BOTH look into the cloud (each must trace shadow rays; with the identity camera the band
+    tile was black): device against oracle under BOTH tie rules.  Under the device's rule ray counts and film are exact; under
     the reference's first-met rule the film stays inside the north-star gate and the ray counts within a few rays."""
     from phosphorus_mk2_amd import scenes, xpu
     xpu.load_library()
-    sc = scenes.multi_material_soup(500_000, width=width, height=height)
+    sc = aim_camera(scenes.multi_material_soup(500_000, width=width, height=height), YAW, PITCH)
     ty = (height // 32) * 32
-    tiles = [(32 * (width // 64), 32 * (height // 64), 32, 32), (32 * 9, ty, 32, height - ty)]
+    a32 = lambda v: (int(v) // 32) * 32
+    tiles = [(a32(0.75 * width), a32(0.5 * height), 32, 32), (a32(0.6 * width), ty, 32, height - ty)]
     dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=9))
     try:
         dev.preprocess(sc)
@@ -160,9 +180,12 @@ def test_bmw_standin_configs_at_their_real_sample_counts(orc, width, height, spp
     try:
         orc.set_tie_rule(1)
         try:
-            ref, ost = O.render(rng=orc.RNG_COUNTER, seed=23, threads=2, tiles=tiles)
+            ref, osts = oracle_render_per_tile(O, tiles, rng=orc.RNG_COUNTER, seed=23, threads=1)
         finally:
             orc.set_tie_rule(0)
+        ost = {k: sum(o[k] for o in osts) for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked")}
+        for (x, y, w, h), o in zip(tiles, osts):  # neither tile is a black one
+            assert o["rays_closest"] > 1.5 * w * h * spp and o["rays_shadow"] > 0.2 * w * h * spp, ((x, y), o)
         ref0, ost0 = O.render(rng=orc.RNG_COUNTER, seed=23, threads=2, tiles=tiles)
     finally:
         O.close()
@@ -176,4 +199,4 @@ def test_bmw_standin_configs_at_their_real_sample_counts(orc, width, height, spp
         fin0 = fin & np.isfinite(b0).all(-1)
         d = a[fin0].astype(np.float64) - b0[fin0].astype(np.float64)
         assert float(np.sqrt((d * d).sum(-1)).max(initial=0.0)) < 1e-4, (x, y)  # the north star's gate, reference tie rule
-    assert float(np.nanmax(film.data[..., :3])) > 0.0 and ost["rays_shadow"] > 0
+        assert float(a[fin].max()) > 0.0, (x, y)  # THIS tile is lit

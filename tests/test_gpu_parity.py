@@ -786,6 +786,30 @@ def test_full_size_properties(xpu, orc):
         assert abs(st[k] - ost0[k]) <= 4, (k, st[k], ost0[k])
 
 
+def test_full_size_frame_with_a_lit_edge_band(xpu, orc):
+    """BASELINE config #2's film (1280x720 = 22 tile rows + a 16-row edge band) with the camera aimed so that the band and the last
+    column look INTO the cloud (conftest.aim_camera: with the identity camera rows 704-720 see nothing): the whole frame
+    against the oracle bit for bit, and the band itself must be lit and must have traced shadow rays."""
+    from conftest import aim_camera
+    from phosphorus_mk2_amd import scenes
+    sc = aim_camera(scenes.soup(100000), 0.5, 0.3)
+    film, st = xpu.render(sc, spp=4, seed=5)
+    O = orc.Oracle(sc, spp=4)
+    orc.set_tie_rule(1)
+    try:
+        ref, ost = O.render(rng=orc.RNG_COUNTER, seed=5, threads=16)
+        band = [(x, 704, 32, 16) for x in range(0, 1280, 32)]
+        _, bst = O.render(rng=orc.RNG_COUNTER, seed=5, threads=16, tiles=band)
+    finally:
+        orc.set_tie_rule(0)
+        O.close()
+    for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_masked"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    assert bits_equal(film[..., :3], ref[..., :3])
+    assert bst["rays_closest"] > 1.3 * 1280 * 16 * 4 and bst["rays_shadow"] > 0.2 * 1280 * 16 * 4, bst  # the band's rays hit the cloud
+    assert (film[704:, 640:, :3].sum(-1) > 0).mean() > 0.08 and (film[:, 1248:, :3].sum(-1) > 0).mean() > 0.2  # band and last column are lit
+
+
 def test_tie_rule_deviation_on_the_1M_soup_is_one_pixel(xpu, orc):
     """The documented deviation, kept measurable: the device gives equal-distance hits to the lowest primitive index, the reference to
     whichever triangle ITS traversal of ITS tree meets first (src/accel/triangle.hpp:166-179).  On Soup(1 M) at 64 spp that costs
@@ -876,6 +900,22 @@ def test_auto_builder_falls_back_to_the_host_only_for_recoverable_failures(xpu, 
     assert "FAILED:" in fat["auto"] and "device BVH build" in fat["auto"] and "FAILED:" in fat["device"] and "fell back" not in fat_err
     again, ast_ = xpu.render(sc, spp=4, seed=2)
     assert ast_["bvh_built_on_device"] == 1 and bits_equal(again, want)
+
+
+def test_destroying_a_device_with_a_frame_in_flight_joins_it(xpu, orc):
+    """phx_dev_destroy after phx_dev_start WITHOUT phx_dev_join (include/phx_xpu.h: destroy joins): the call returns when the frame has
+    ended, every tile has been delivered through the add_tile callback by then, and the film is the one a joined frame gives."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.soup(20000, width=160, height=96)
+    ref, _ = xpu.render(sc, spp=16, seed=3)
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=16, paths_per_sample=1, path_depth=9))
+    dev.preprocess(sc)
+    film = xpu.Film(160, 96, 4)
+    dev.start(sc, xpu.FrameState(3, xpu.Tiles.make(160, 96, 32), film))  # the Python add_tile callback: fires from the driver thread
+    dev.close()                                                          # no join()
+    assert bits_equal(film.data[..., :3], ref[..., :3])
+    dev2 = xpu.HipDevice.make(xpu.Options(samples_per_pixel=4, paths_per_sample=1, path_depth=9))  # and the process can go on making devices
+    dev2.preprocess(sc); dev2.close()
 
 
 def test_watchdog_fails_the_frame_instead_of_hanging(xpu, orc):
