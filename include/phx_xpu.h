@@ -233,6 +233,8 @@ typedef struct phx_stats {
   uint64_t primary_tri_tests;  /* instrumented: triangles a packet reached (each is tested by its 64 lanes), summed */
   uint64_t primary_tri_lanes_hit; /* instrumented: lanes whose closest hit a triangle test improved, summed */
   uint64_t device_bytes;       /* HBM this device object holds right now: tree, scene tables, ray / hit / shadow queues, path state, batch buffer */
+  uint64_t tri_pairs_pending;  /* instrumented: pending (ray, triangle) pairs of a wave at its triangle-block executions, summed (each execution tests one per pending lane) */
+  uint64_t tri_pairs_hist[8];  /* instrumented: those executions by the wave's pending pairs: <= 8, 16, 24, 32, 48, 64, 96, more */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

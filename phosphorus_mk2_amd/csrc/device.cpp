@@ -704,7 +704,7 @@ void phx_device::driver_loop() {
     {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [this]() { return frame_pending || quit; });
-      if (quit) return;
+      if (!frame_pending) return;  // quit, and no frame handed over: a frame that WAS started is rendered first (phx_dev_destroy joins it, include/phx_xpu.h)
       frame_pending = false;
     }
     const int st = guarded([this]() { return run_frame(); });
@@ -800,7 +800,8 @@ int phx_device::run_frame() {
   stats.instrumented = launch_counts_traversal_work() ? 1 : 0;
   stats.wave_iters = ds.wave_iters; stats.node_block_execs = ds.node_block_execs; stats.tri_block_execs = ds.tri_block_execs; stats.refills = ds.refills;
   stats.idle_lane_iters = ds.idle_lane_iters; stats.tri_pending_lane_iters = ds.tri_pending_lane_iters;
-  for (int k = 0; k < 8; ++k) stats.stack_pushes[k] = ds.stack_pushes[k];
+  for (int k = 0; k < 8; ++k) { stats.stack_pushes[k] = ds.stack_pushes[k]; stats.tri_pairs_hist[k] = ds.tri_pairs_hist[k]; }
+  stats.tri_pairs_pending = ds.tri_pairs_pending;
   stats.primary_packets = ds.primary_packets; stats.primary_fallbacks = ds.primary_fallbacks; stats.primary_node_tests = ds.primary_node_tests;
   stats.primary_tri_tests = ds.primary_tri_tests; stats.primary_tri_lanes_hit = ds.primary_tri_lanes_hit;
   if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace / k_shade_g: " + std::to_string(ds.watchdog) + " wave(s) hit a watchdog (traversal iterations, or a wait on the shade kernel's append ring): the frame is incomplete");

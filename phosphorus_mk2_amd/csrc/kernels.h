@@ -69,7 +69,10 @@ struct DevStats {
   // per PACKET (one test serves the 64 rays), and lanes whose ray was improved by a triangle test (of 64 per test)
   unsigned long long primary_packets, primary_fallbacks, primary_node_tests, primary_tri_tests, primary_tri_lanes_hit;
   unsigned long long watchdog;         // k_trace waves that gave up after PHX_TRACE_WATCHDOG iterations: 0, or the frame is reported as failed
-  unsigned long long stack_pushes[8];  // instrumented: pushes onto the per-lane group stack by the depth they land at (7 = 7 and deeper)  // instrumented: lanes without a ray / with triangles still pending at the node block, summed over iterations
+  unsigned long long stack_pushes[8];  // instrumented: pushes onto the per-lane group stack by the depth they land at (7 = 7 and deeper)
+  // instrumented: pending (ray, triangle) pairs of the wave at its triangle-block executions — their sum, and executions by the number of
+  // pairs: <= 8, <= 16, <= 24, <= 32, <= 48, <= 64, <= 96, more
+  unsigned long long tri_pairs_pending, tri_pairs_hist[8];
 };
 
 struct PassBuffers {

@@ -208,6 +208,9 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
   uint32_t cnt_iter = 0, cnt_nb = 0, cnt_tb = 0, cnt_refill = 0;              // ... and the wave's (wave-uniform)
   uint32_t cnt_idle = 0, cnt_pend = 0;
   uint32_t cnt_push[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // pending (ray, triangle) pairs of the WAVE when its triangle block runs — each lane tests one of its own per execution; a block that
+  // handed pairs to idle lanes could test up to 64 (profiles/r06_tri_handoff.md) — summed, and as a histogram
+  uint32_t cnt_pairs = 0, cnt_pairs_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   uint32_t guard = 0;  // wave-uniform (an SGPR): iterations of this wave
   for (;;) {
@@ -387,7 +390,14 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     // ---- one triangle test per lane that has one pending
     const bool tpend = active && (tg & TG_PENDING);
 #if PHX_COUNT
-    if (__ballot(tpend)) ++cnt_tb;
+    if (__ballot(tpend)) {
+      ++cnt_tb;
+      const uint32_t mine = active ? (uint32_t)__popc((tg >> 8) & 0xffu) + (uint32_t)__popc((tq >> 8) & 0xffu) : 0u;  // <= 16
+      uint32_t pairs = 0;
+      for (uint32_t b = 0; b < 5u; ++b) pairs += (uint32_t)__popcll(__ballot((mine >> b) & 1u)) << b;
+      cnt_pairs += pairs;
+      ++cnt_pairs_hist[pairs <= 8u ? 0 : pairs <= 16u ? 1 : pairs <= 24u ? 2 : pairs <= 32u ? 3 : pairs <= 48u ? 4 : pairs <= 64u ? 5 : pairs <= 96u ? 6 : 7];
+    }
 #endif
     if (tpend) {
       const uint32_t k = 23u - (uint32_t)__clz((int)(tg & TG_PENDING));  // slot of the highest pending triangle (bits 8..15 -> 7..0)
@@ -446,6 +456,8 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
     atomicAdd(&pb.stats->refills, (unsigned long long)cnt_refill);
     atomicAdd(&pb.stats->idle_lane_iters, (unsigned long long)cnt_idle);
     atomicAdd(&pb.stats->tri_pending_lane_iters, (unsigned long long)cnt_pend);
+    atomicAdd(&pb.stats->tri_pairs_pending, (unsigned long long)cnt_pairs);
+    for (int k = 0; k < 8; ++k) if (cnt_pairs_hist[k]) atomicAdd(&pb.stats->tri_pairs_hist[k], (unsigned long long)cnt_pairs_hist[k]);
   }
 #endif
 }
@@ -981,6 +993,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #ifndef PHX_SHADE_RING
 #define PHX_SHADE_RING 1
 #endif
+#ifndef PHX_SHADE_DYN_SLICES
+#define PHX_SHADE_DYN_SLICES 1  /* with the ring: a wave takes the next 64 sorted slots of the window from an LDS counter instead of slots [k x BLOCK + 64 w, + 64) of round k (nothing orders the waves inside a window any more, so the fast ones take more) */
+#endif
 #ifndef PHX_RING_BLK
 #define PHX_RING_BLK 256u  /* entries per flush = per global atomic (the counters sustain ~80 returning atomics per us and address: 256 keeps the kernel near 50) */
 #endif
@@ -1066,6 +1081,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   __shared__ float4 ring_a[2 * 2 * PHX_RING_BLK];  // survivors: (o, path | SPECULAR << 31), (d, tmax)
   __shared__ float4 ring_b[3 * 2 * PHX_RING_BLK];  // NEE rays: (o, path), (d, tmax), (beta * Li)
   __shared__ RingCtl ring_ctl[2];
+  __shared__ uint32_t slice_next;  // PHX_SHADE_DYN_SLICES: the window's next 64-slot slice
   if (threadIdx.x < sizeof(ring_ctl) / 4u) reinterpret_cast<uint32_t*>(ring_ctl)[threadIdx.x] = 0u;  // visible after the first barrier every thread reaches
 #else
   __shared__ uint32_t lds_sr[2 * ((BLOCK >> 6) + 1)];
@@ -1102,6 +1118,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     PHX_PHASE(5)  // (the barrier at the end of the previous window, loop overhead)
     // ---- counting sort of the window by material, through LDS
     if (threadIdx.x < NB + 2) bucket[threadIdx.x] = 0;
+#if PHX_SHADE_RING && PHX_SHADE_DYN_SLICES
+    if (threadIdx.x == 0) slice_next = 0u;
+#endif
     __syncthreads();
     uint32_t keys[ITEMS];
     { uint32_t tri_[ITEMS]; request_tris(base, tri_); request_keys(tri_, keys); }
@@ -1133,10 +1152,23 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     // across the closure code: 5-12 VGPRs where the kernel has none to spare, 1.2 of 42.7 ms: profiles/r03_q_prefetch_ab.log.)
     uint32_t next_i = 0; bool next_live = false;
     float4 next_h = make_float4(0.f, 0.f, 0.f, 0.f), next_a = next_h, next_b = next_h;
-    auto request_round = [&](int k) {
+    constexpr bool DYN = PHX_SHADE_RING && PHX_SHADE_DYN_SLICES;
+    // DYN: slices of 64 sorted slots, handed out by an LDS counter; the live slots are a prefix of the sorted window, so are the live slices
+    const uint32_t nslices = (min((uint32_t)WINDOW, count - base) + 63u) >> 6;
+    auto take_slice = [&]() -> uint32_t {
+#if PHX_SHADE_RING && PHX_SHADE_DYN_SLICES
+      uint32_t s_ = 0;
+      if (__lane_id() == 0) s_ = __hip_atomic_fetch_add(&slice_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return PHX_UNI(s_);
+#else
+      return 0u;
+#endif
+    };
+    auto sorted_slot = [&](uint32_t k) { return DYN ? k * 64u + __lane_id() : k * BLOCK + threadIdx.x; };  // k: slice (DYN) or round
+    auto request_round = [&](uint32_t k) {
       next_live = false;
-      if (k < ITEMS && base + (uint32_t)k * BLOCK < count) {
-        next_i = base + perm[k * BLOCK + threadIdx.x];
+      if (DYN ? k < nslices : (k < (uint32_t)ITEMS && base + k * BLOCK < count)) {
+        next_i = base + perm[sorted_slot(k)];
         next_live = next_i < count;
         if (next_live) {
           next_h = pb.hit[next_i];
@@ -1158,13 +1190,15 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     // (with per-hit closure weights — glass — either stage costs the kernel 16 B of scratch and buys nothing: 41.7-42.1 ms with, 41.9-42.2
     // without on the glass showroom, profiles/r05_c_shade_prefetch_glass_ab.log: those instantiations request where they consume)
     constexpr bool STAGE1 = PHX_SHADE_PREFETCH >= 1 && !PERHIT, STAGE2 = PHX_SHADE_PREFETCH >= 2 && !PERHIT;
-    if constexpr (STAGE1) request_round(0);
+    uint32_t k = DYN ? take_slice() : 0u, k_next = 0u;
+    if constexpr (STAGE1) request_round(k);
     if constexpr (STAGE2) request_round_dependents();
-    for (int k = 0; k < ITEMS; ++k) {
-      if (base + (uint32_t)k * BLOCK >= count) break;  // workgroup-uniform: the slots past the end of the queue sort behind every live one
+    for (;; k = k_next) {
+      // wave-uniform (DYN) / workgroup-uniform: the slots past the end of the queue sort behind every live one
+      if (DYN ? k >= nslices : (k >= (uint32_t)ITEMS || base + k * BLOCK >= count)) break;
       // (instantiations without a stage request each record where it is consumed, exactly as the round-4 kernel did)
       if constexpr (STAGE1 && !STAGE2) request_round_dependents();
-      const uint32_t i = STAGE1 ? next_i : base + perm[k * BLOCK + threadIdx.x];
+      const uint32_t i = STAGE1 ? next_i : base + perm[sorted_slot(k)];
       const bool live = STAGE1 ? next_live : i < count;
       // Live ranges are kept short on purpose (the kernel is register-bound: 128 VGPRs as one block of code): radiance and the
       // normals channel are written as soon as the hit is known; the light's record is re-read after the closure evaluation instead
@@ -1319,7 +1353,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
         PHX_PHASE(3)  // roulette, bsdf_sample, path state store
-        if constexpr (STAGE1) request_round(k + 1);  // in flight across the append (the append waits for LDS traffic only)
+        k_next = DYN ? take_slice() : k + 1u;
+        if constexpr (STAGE1) request_round(k_next);  // in flight across the append (the append waits for LDS traffic only)
 #if PHX_SHADE_RING
         {
           const v3 nxt_o = p + n * off;

@@ -31,5 +31,8 @@ nv = sum(st["node_visits_lds"]) + sum(st["node_visits_mem"]); tt = sum(st["tri_t
 out["wave"] = {"iterations": st["wave_iters"], "node_block_execs": st["node_block_execs"], "tri_block_execs": st["tri_block_execs"], "refills": st["refills"], "idle_lanes_per_iteration": st["idle_lane_iters"] / max(1, st["wave_iters"]), "tri_pending_lanes_per_iteration": st["tri_pending_lane_iters"] / max(1, st["wave_iters"]),
                "lanes_per_node_block": nv / max(1, st["node_block_execs"]), "lanes_per_tri_block": tt / max(1, st["tri_block_execs"]),
                "iterations_per_ray_x64": st["wave_iters"] * 64 / rays,
-               "stack_pushes_per_ray_by_depth": [x / rays for x in st["stack_pushes"]]}
+               "stack_pushes_per_ray_by_depth": [x / rays for x in st["stack_pushes"]],
+               # pending (ray, triangle) pairs of the wave when its triangle block runs (it tests one per pending lane): profiles/r06_tri_handoff.md
+               "pending_pairs_per_tri_block": st["tri_pairs_pending"] / max(1, st["tri_block_execs"]),
+               "tri_blocks_by_pending_pairs": dict(zip(("<=8", "<=16", "<=24", "<=32", "<=48", "<=64", "<=96", ">96"), [x / max(1, st["tri_block_execs"]) for x in st["tri_pairs_hist"]]))}
 print(json.dumps(out))
