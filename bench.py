@@ -461,10 +461,12 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
            "bvh_bytes": st["bvh_bytes"], "bvh_build_ms": st["bvh_build_ms"], "preprocess_s": pre, "paths_in_flight": st["paths_in_flight"], "hbm_bytes": st["device_bytes"],
            "plan": {"block": st["trace_block"], "ntop": st["trace_ntop"], "levels": st["trace_levels"]},
            "kernel_ms_per_step": kernel_ms(acc, steps), "film_finite": bool(np.isfinite(film).all()),
-           # (general-closure scenes at thousands of samples per pixel: a few pixels of 8 M collect ONE non-finite sample.  Where: listed here,
-           # so that their tiles can be rendered with the oracle — scripts/nonfinite_probe.py does, and the masks must be equal: the sample is the
-           # restated arithmetic's, not the device's.  NOT "a light seen edge-on": |n_L . wi| = 0 gives pdf = inf and a ZERO contribution, in
-           # li() (spt.hpp:253-255) and here; a non-finite value needs a non-finite f or a pdf of 0)
+           # (general-closure scenes at thousands of samples per pixel: a few pixels of 8 M collect ONE NaN sample, listed here.  Its origin
+           # (scripts/nonfinite_probe.py, profiles/r06_nonfinite_probe_*.json: the oracle has the SAME pixels, every finite pixel of their tiles
+           # is bit-equal, and the one sample of each is found by bisection): the sheen lobe.  A direction within rounding of the shading normal
+           # has cos(theta) = 1 + 1 ulp, and Lambda = exp(2 L(0.5) - L(1 - cos theta)) (src/bsdf/sheen.hpp:51-64) raises the negative
+           # 1 - cos(theta) to a fractional power.  The reference has no guard; the restatement and the device reproduce it
+           # (tests/test_gpu_parity.py::test_sheen_is_nan_for_a_direction_on_the_normal_...).  NOT "a light seen edge-on", as round 5 wrote.)
            "film_finite_fraction": float(np.isfinite(film).all(-1).mean()),
            "nonfinite_pixels_xy": [[int(x), int(y)] for y, x in np.argwhere(~np.isfinite(film).all(-1))[:32]]}
     tag = workload_tag(kind, triangles, width, height, args.depth)

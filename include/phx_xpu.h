@@ -235,6 +235,7 @@ typedef struct phx_stats {
   uint64_t device_bytes;       /* HBM this device object holds right now: tree, scene tables, ray / hit / shadow queues, path state, batch buffer */
   uint64_t tri_pairs_pending;  /* instrumented: pending (ray, triangle) pairs of a wave at its triangle-block executions, summed (each execution tests one per pending lane) */
   uint64_t tri_pairs_hist[8];  /* instrumented: those executions by the wave's pending pairs: <= 8, 16, 24, 32, 48, 64, 96, more */
+  uint64_t trace_stack_packed; /* 1: k_trace keeps 5-byte stack entries in LDS (deep trees: more of the tree is staged), 0: 8-byte entries */
 } phx_stats;
 
 typedef struct phx_device phx_device; /* opaque */

@@ -100,7 +100,7 @@ class Stats(C.Structure):
         ("refills", C.c_uint64), ("idle_lane_iters", C.c_uint64), ("tri_pending_lane_iters", C.c_uint64), ("stack_pushes", C.c_uint64 * 8), ("bvh_cost_model", C.c_double), ("trace_lds_levels", C.c_uint64), ("bvh_built_on_device", C.c_uint64),
         ("shade_kernel_ms", C.c_double), ("shade_launches", C.c_uint64), ("shade_general", C.c_uint64), ("primary_ms", C.c_double), ("primary_launches", C.c_uint64),
         ("primary_packets", C.c_uint64), ("primary_fallbacks", C.c_uint64), ("primary_node_tests", C.c_uint64), ("primary_tri_tests", C.c_uint64), ("primary_tri_lanes_hit", C.c_uint64),
-        ("device_bytes", C.c_uint64), ("tri_pairs_pending", C.c_uint64), ("tri_pairs_hist", C.c_uint64 * 8),
+        ("device_bytes", C.c_uint64), ("tri_pairs_pending", C.c_uint64), ("tri_pairs_hist", C.c_uint64 * 8), ("trace_stack_packed", C.c_uint64),
     ]
 
 

@@ -549,7 +549,7 @@ int phx_dev_get_stats(const phx_device* d, phx_stats* out) {
   *out = d->stats;
   out->bvh_nodes = d->bvh_nodes; out->bvh_bytes = d->bvh_bytes; out->triangles = d->num_triangles;
   out->preprocess_ms = d->preprocess_ms; out->bvh_build_ms = d->bvh_build_ms;
-  out->trace_block = d->plan.block; out->trace_ntop = d->plan.ntop; out->trace_levels = d->plan.levels; out->trace_lds_levels = d->plan.lds_levels;
+  out->trace_block = d->plan.block; out->trace_ntop = d->plan.ntop; out->trace_levels = d->plan.levels; out->trace_lds_levels = d->plan.lds_levels; out->trace_stack_packed = d->plan.packed;
   out->trace_waves_per_cu = (uint64_t)d->plan.wg_per_cu * (d->plan.block / 64u); out->bvh_depth = d->scene.stack_levels;
   out->paths_in_flight = d->paths_in_flight;
   out->bvh_cost_model = d->bvh_cost_model; out->bvh_built_on_device = d->bvh_built_on_device;

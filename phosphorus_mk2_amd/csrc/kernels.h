@@ -94,7 +94,7 @@ struct PassBuffers {
 };
 
 // shape of a k_trace launch on a scene (reported through phx_stats so that tests can assert which plan a tree ran with)
-struct TracePlan { uint32_t block, ntop, levels, lds_bytes, wg_per_cu, lds_levels, spill_threads; };
+struct TracePlan { uint32_t block, ntop, levels, lds_bytes, wg_per_cu, lds_levels, spill_threads, packed /* 5-byte stack entries in LDS */; };
 TracePlan trace_plan(const DevScene& sc);
 // per device, once: lets the traversal kernels use the CU's full 160 KB of LDS as dynamic shared memory
 hipError_t init_kernels_on_current_device();

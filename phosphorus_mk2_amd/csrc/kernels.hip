@@ -164,6 +164,15 @@ struct LdsStack {
 #ifndef PHX_SPILL_LDS_LEVELS
 #define PHX_SPILL_LDS_LEVELS 7u
 #endif
+#ifndef PHX_STACK_PACKED
+// Deep trees (the SPILL plan: >= 10 stack levels, 7 of them in LDS) keep 5-byte stack entries in LDS — (child base : 24 | pending inner hits : 8)
+// as a dword + the node's valid mask as a byte, four levels of a lane sharing one dword — instead of 8-byte ones; the 21 KB this frees per
+// workgroup stage 256 more nodelets (281 -> 537).  Measured (profiles/r06_f_packed_stack_ab.log): k_trace -2.3 % on BASELINE config 4 (10 M
+// triangles), -4.0 % on the closed showroom (depth 13); trees whose stacks fit LDS gain nothing from more staged nodelets (100 k: +0.7 %, the
+// second LDS access per push / pop; 1 M: +-0) and keep 8-byte entries.  Pools of < 2^24 elements only (1 GB; larger ones: 8-byte entries).
+// 0 = never, 1 = the SPILL plan, 2 = every plan (A/B).
+#define PHX_STACK_PACKED 1
+#endif
 #ifndef PHX_PROBE_VALU
 #define PHX_PROBE_VALU 0
 #endif
@@ -183,9 +192,9 @@ struct DynQueue {            // the launch is persistent and every WAVE pulls ch
   uint32_t num_waves;
   uint32_t* cursor;          // pb.counters + CNT_CURSOR: two global cursors, zeroed by the kernel that filled the queues
 };
-template <int BLOCK, bool SPILL /* the stack's deep levels live in HBM */>
+template <int BLOCK, bool SPILL /* the stack's deep levels live in HBM */, bool PACKED /* 5-byte stack entries in LDS */>
 __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffers& pb, int q,
-                                             uint32_t* cursor /* LDS: the workgroup's ranges */, uint2* stack_base, uint32_t lds_levels,
+                                             uint32_t* cursor /* LDS: the workgroup's ranges */, uint2* stack_base, uint8_t* stack_valid /* PHX_STACK_PACKED: this thread's dword of the valid-mask rows */, uint32_t lds_levels,
                                              uint2* spill_base /* this thread's column of sc.stack_spill */, uint32_t refill_min,
                                              const uint4* __restrict__ top /* nodelets staged in LDS */, uint32_t ntop,
                                              const DynQueue dq, const uint8_t* __restrict__ perm_lut) {
@@ -327,7 +336,12 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
         ++cnt_push[sp < 7 ? sp : 7];
 #endif
         // SPILL: the top lds_levels entries of the stack live in LDS, the rare deeper ones in HBM (sc.stack_spill)
-        if (!SPILL || (uint32_t)sp < lds_levels) stack_base[sp * BLOCK] = make_uint2(ng_base, rest);
+        if (!SPILL || (uint32_t)sp < lds_levels) {
+          if constexpr (PACKED) {
+            reinterpret_cast<uint32_t*>(stack_base)[sp * BLOCK] = (ng_base & 0x00ffffffu) | (rest & 0xff000000u);
+            stack_valid[((uint32_t)sp >> 2) * (BLOCK * 4u) + ((uint32_t)sp & 3u)] = (uint8_t)rest;   // four levels share a lane's dword: the access pattern of a 4-byte column
+          } else stack_base[sp * BLOCK] = make_uint2(ng_base, rest);
+        }
         else spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride] = make_uint2(ng_base, rest);
         ++sp;
       }
@@ -436,7 +450,13 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
       } else {
         --sp;
         uint2 e;
-        if (!SPILL || (uint32_t)sp < lds_levels) e = stack_base[sp * BLOCK];
+        if (!SPILL || (uint32_t)sp < lds_levels) {
+          if constexpr (PACKED) {
+            const uint32_t word = reinterpret_cast<uint32_t*>(stack_base)[sp * BLOCK];
+            const uint32_t vb = stack_valid[((uint32_t)sp >> 2) * (BLOCK * 4u) + ((uint32_t)sp & 3u)];
+            e = make_uint2(word & 0x00ffffffu, (word & 0xff000000u) | vb);
+          } else e = stack_base[sp * BLOCK];
+        }
         else e = spill_base[(size_t)((uint32_t)sp - lds_levels) * sc.spill_stride];
         ng_base = e.x; ng_hits = e.y;
       }
@@ -472,13 +492,16 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
 //   with per-wave global chunks 512 rays were the optimum, 64-ray chunks were atomic-bound).  A wave
 //   drains once per launch, not once per slice, and a slow image region is shared by everyone.
 // Dynamic LDS layout: [ntop pool elements x 80 B][levels x BLOCK stack entries x 8 B][12 cursor words][2 KB octant table].
-template <int BLOCK, bool SPILL = false>
+template <int BLOCK, bool SPILL = false, bool PACKED = false>
 __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb, int q, int sq, int do_closest, int do_shadow, uint32_t refill_min,
                                                  uint32_t ntop, uint32_t levels, uint32_t min_chunks, uint32_t target_chunks) {
   extern __shared__ uint4 smem[];
   uint4* top = smem;
   uint2* stack = reinterpret_cast<uint2*>(smem + ntop * (PHX_NODE_LDS_BYTES / 16u));
-  uint32_t* cursor = reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
+  // PACKED: [levels x BLOCK dwords][ceil(levels / 4) x BLOCK dwords of valid bytes]: 4 + 1 bytes per entry
+  uint32_t* stack_words = reinterpret_cast<uint32_t*>(stack);
+  uint32_t* valid_rows = stack_words + levels * BLOCK;
+  uint32_t* cursor = PACKED ? valid_rows + ((levels + 3u) >> 2) * BLOCK : reinterpret_cast<uint32_t*>(stack + levels * BLOCK);
   uint8_t* perm_lut = reinterpret_cast<uint8_t*>(cursor + 12);  // PHX_PERM_LUT: 8 octants x 256 masks (cursor: 12 words)
   const uint32_t n_closest = do_closest ? pb.counters[q * CNT_STRIDE] : 0u;
   const uint32_t n_shadow = do_shadow ? pb.counters[CNT_SHADOW + sq * CNT_STRIDE] : 0u;
@@ -523,8 +546,12 @@ __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb,
   for (uint32_t i = threadIdx.x; i < 2048u; i += BLOCK) perm_lut[i] = (uint8_t)perm_xor8(i & 0xffu, i >> 8);
 #endif
   __syncthreads();
-  trace_stream<BLOCK, SPILL>(sc, pb, q, cursor, stack + threadIdx.x, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
-                                  refill_min, top, ntop, dq, perm_lut);
+  if constexpr (PACKED)
+    trace_stream<BLOCK, SPILL, true>(sc, pb, q, cursor, reinterpret_cast<uint2*>(stack_words + threadIdx.x), reinterpret_cast<uint8_t*>(valid_rows + threadIdx.x), levels,
+                                     sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x, refill_min, top, ntop, dq, perm_lut);
+  else
+    trace_stream<BLOCK, SPILL, false>(sc, pb, q, cursor, stack + threadIdx.x, nullptr, levels, sc.stack_spill + (size_t)blockIdx.x * BLOCK + threadIdx.x,
+                                      refill_min, top, ntop, dq, perm_lut);
 }
 
 // stage-level hook (phx_dev_trace): one ray per lane run to completion with the plain traverse8 loop of bvh8.h.  The per-lane
@@ -1016,62 +1043,97 @@ __device__ __forceinline__ void ring_flush(const float4* ring /* [NREC][2 x BLK]
     if (NREC == 3) g2[gb + k] = ring[4u * PHX_RING_BLK + first + k];
   }
 }
-template <int NREC>
-__device__ __forceinline__ void ring_append(bool want, const float4& r0, const float4& r1, const float4& r2, RingCtl* ctl, float4* ring,
-                                            uint32_t* gcounter, float4* g0, float4* g1, float4* g2, unsigned long long* watchdog) {
-  constexpr uint32_t BLK = PHX_RING_BLK;
-  static_assert((BLK & (BLK - 1u)) == 0u && BLK >= 64u, "a wave's reservation spans at most two blocks");
-  const unsigned long long mask = __ballot(want);
-  if (mask == 0ull) return;  // wave-uniform
-  const uint32_t lane = __lane_id(), n = (uint32_t)__popcll(mask);
-  uint32_t pos = 0;
-  if (lane == 0) pos = __hip_atomic_fetch_add(&ctl->head, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  pos = PHX_UNI(pos);
-  const uint32_t gen0 = pos / BLK, gen1 = (pos + n - 1u) / BLK;  // generation g lives in buffer g & 1; it is that buffer's (g >> 1)-th use
-  // (a wait is rare: the block after next fills a whole round later than this one's flush starts.  Every wait is bounded — PHX_RING_SPINS
-  // sleeps of 64 clocks, ~30 ms — after which the wave counts itself in DevStats::watchdog and goes on: the frame is then reported as failed
-  // (device.cpp), exactly as for k_trace's watchdog; no wave can spin for ever.)
+// One wave's append to BOTH rings.  The steps of the two queues are interleaved so that their LDS round trips overlap: both reservations, then
+// both sets of records, then both commits — three waits on the LDS instead of six.
+struct RingSlot { unsigned long long mask; uint32_t n, pos, gen0, gen1; };
+__device__ __forceinline__ bool ring_wait(RingCtl* ctl, const RingSlot& t, unsigned long long* watchdog) {
+  // a block is written again only after its flush.  (A wait is rare: the block after next fills a whole round later than this one's flush
+  // starts.  Every wait is bounded — PHX_RING_SPINS sleeps of 64 clocks, ~30 ms — after which the wave counts itself in DevStats::watchdog,
+  // marks the workgroup's ring dead and drops its records: the frame is then reported as failed (device.cpp), as for k_trace's watchdog; no
+  // wave can spin for ever.)
   uint32_t spins = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const uint32_t gen = h ? gen1 : gen0;
-    if (h && gen1 == gen0) break;
+    const uint32_t gen = h ? t.gen1 : t.gen0;  // generation g lives in buffer g & 1; it is that buffer's (g >> 1)-th use
+    if (h && t.gen1 == t.gen0) break;
     while (PHX_UNI(__hip_atomic_load(&ctl->flushed[gen & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (gen >> 1)) {
       if (++spins > PHX_RING_SPINS || PHX_UNI(__hip_atomic_load(&ctl->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
-        if (lane == 0) { atomicAdd(watchdog, 1ull); __hip_atomic_store(&ctl->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        return;
+        if (__lane_id() == 0) { atomicAdd(watchdog, 1ull); __hip_atomic_store(&ctl->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        return false;
       }
       __builtin_amdgcn_s_sleep(1);
     }
   }
-  asm volatile("" ::: "memory");
-  if (want) {
-    const uint32_t idx = (pos + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & (2u * BLK - 1u);
-    ring[idx] = r0; ring[2u * BLK + idx] = r1;
-    if (NREC == 3) ring[4u * BLK + idx] = r2;
-  }
-  PHX_LDS_ORDER();  // the records are in LDS before the commit
-  const uint32_t n0 = min(n, (gen0 + 1u) * BLK - pos), n1 = n - n0;
-  uint32_t c0 = 0, c1 = 0;
-  if (lane == 0) {
-    c0 = __hip_atomic_fetch_add(&ctl->committed[gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (n1) c1 = __hip_atomic_fetch_add(&ctl->committed[gen1 & 1u], n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  c0 = PHX_UNI(c0); c1 = PHX_UNI(c1);
+  return true;
+}
+template <int NREC>
+__device__ __forceinline__ void ring_finish(RingCtl* ctl, const float4* ring, const RingSlot& t, uint32_t c0, uint32_t c1, uint32_t* gcounter, float4* g0, float4* g1, float4* g2) {
+  constexpr uint32_t BLK = PHX_RING_BLK;
+  const uint32_t n0 = min(t.n, (t.gen0 + 1u) * BLK - t.pos), n1 = t.n - n0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const uint32_t gen = h ? gen1 : gen0;
+    const uint32_t gen = h ? t.gen1 : t.gen0;
     if (h ? (n1 != 0u && c1 + n1 == BLK) : (c0 + n0 == BLK)) {  // this wave's commit completed the block: it flushes it
       asm volatile("" ::: "memory");
       ring_flush<NREC>(ring, (gen & 1u) * BLK, BLK, gcounter, g0, g1, g2);
       PHX_LDS_ORDER();  // the block has been read before it is handed back
-      if (lane == 0) {
+      if (__lane_id() == 0) {
         __hip_atomic_store(&ctl->committed[gen & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         PHX_LDS_ORDER();
         __hip_atomic_fetch_add(&ctl->flushed[gen & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
+}
+__device__ __forceinline__ void ring_append2(bool want_a, const float4& a0, const float4& a1, RingCtl* ctl_a, float4* ring_a, uint32_t* gcounter_a, float4* ga0, float4* ga1,
+                                             bool want_b, const float4& b0, const float4& b1, const float4& b2, RingCtl* ctl_b, float4* ring_b, uint32_t* gcounter_b, float4* gb0, float4* gb1, float4* gb2,
+                                             unsigned long long* watchdog) {
+  constexpr uint32_t BLK = PHX_RING_BLK;
+  static_assert((BLK & (BLK - 1u)) == 0u && BLK >= 64u, "a wave's reservation spans at most two blocks");
+  RingSlot A, B;
+  A.mask = __ballot(want_a); B.mask = __ballot(want_b);
+  A.n = (uint32_t)__popcll(A.mask); B.n = (uint32_t)__popcll(B.mask);
+  if ((A.mask | B.mask) == 0ull) return;  // wave-uniform
+  const uint32_t lane = __lane_id();
+  // ---- reserve: one ds_add_rtn per queue, both in flight
+  uint32_t pa = 0, pb = 0;
+  if (lane == 0) {
+    if (A.n) pa = __hip_atomic_fetch_add(&ctl_a->head, A.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (B.n) pb = __hip_atomic_fetch_add(&ctl_b->head, B.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  A.pos = PHX_UNI(pa); B.pos = PHX_UNI(pb);
+  A.gen0 = A.pos / BLK; A.gen1 = (A.pos + max(A.n, 1u) - 1u) / BLK;
+  B.gen0 = B.pos / BLK; B.gen1 = (B.pos + max(B.n, 1u) - 1u) / BLK;
+  const bool ok_a = A.n != 0u && ring_wait(ctl_a, A, watchdog), ok_b = B.n != 0u && ring_wait(ctl_b, B, watchdog);
+  asm volatile("" ::: "memory");
+  // ---- the records
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (ok_a && want_a) {
+    const uint32_t idx = (A.pos + (uint32_t)__popcll(A.mask & below)) & (2u * BLK - 1u);
+    ring_a[idx] = a0; ring_a[2u * BLK + idx] = a1;
+  }
+  if (ok_b && want_b) {
+    const uint32_t idx = (B.pos + (uint32_t)__popcll(B.mask & below)) & (2u * BLK - 1u);
+    ring_b[idx] = b0; ring_b[2u * BLK + idx] = b1; ring_b[4u * BLK + idx] = b2;
+  }
+  PHX_LDS_ORDER();  // the records are in LDS before the commits
+  // ---- commit: up to two counters per queue (a reservation may straddle two blocks), all in flight together
+  uint32_t ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0;
+  if (lane == 0) {
+    if (ok_a) {
+      const uint32_t n0 = min(A.n, (A.gen0 + 1u) * BLK - A.pos);
+      ca0 = __hip_atomic_fetch_add(&ctl_a->committed[A.gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (A.n != n0) ca1 = __hip_atomic_fetch_add(&ctl_a->committed[A.gen1 & 1u], A.n - n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (ok_b) {
+      const uint32_t n0 = min(B.n, (B.gen0 + 1u) * BLK - B.pos);
+      cb0 = __hip_atomic_fetch_add(&ctl_b->committed[B.gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (B.n != n0) cb1 = __hip_atomic_fetch_add(&ctl_b->committed[B.gen1 & 1u], B.n - n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  ca0 = PHX_UNI(ca0); ca1 = PHX_UNI(ca1); cb0 = PHX_UNI(cb0); cb1 = PHX_UNI(cb1);
+  if (ok_b) ring_finish<3>(ctl_b, ring_b, B, cb0, cb1, gcounter_b, gb0, gb1, gb2);
+  if (ok_a) ring_finish<2>(ctl_a, ring_a, A, ca0, ca1, gcounter_a, ga0, ga1, nullptr);
 }
 template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
@@ -1358,10 +1420,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #if PHX_SHADE_RING
         {
           const v3 nxt_o = p + n * off;
-          ring_append<3>(want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
-                         &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->watchdog);
-          ring_append<2>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
-                         &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr, &pb.stats->watchdog);
+          ring_append2(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX),
+                       &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1],
+                       want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
+                       &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->watchdog);
         }
         PHX_PHASE(4)  // the append: slot reservation, records to LDS, commit; for one wave in BLK / 64 rounds the flush of a block
         if constexpr (STAGE2) request_round_dependents();
@@ -1523,7 +1585,10 @@ const TraceEnv& trace_env() {
 template <typename F>
 void for_each_trace_kernel(F&& f) {
   f(reinterpret_cast<const void*>(&k_trace<256>)); f(reinterpret_cast<const void*>(&k_trace<512>)); f(reinterpret_cast<const void*>(&k_trace<1024>));
-  f(reinterpret_cast<const void*>(&k_trace<1024, true>));
+  f(reinterpret_cast<const void*>(&k_trace<1024, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, true, true>));
+#if PHX_STACK_PACKED >= 2
+  f(reinterpret_cast<const void*>(&k_trace<256, false, true>)); f(reinterpret_cast<const void*>(&k_trace<512, false, true>)); f(reinterpret_cast<const void*>(&k_trace<1024, false, true>));
+#endif
   f(reinterpret_cast<const void*>(&k_trace_rays<true>)); f(reinterpret_cast<const void*>(&k_trace_rays<false>));
   f(reinterpret_cast<const void*>(&k_trace_primary<1>)); f(reinterpret_cast<const void*>(&k_trace_primary<2>)); f(reinterpret_cast<const void*>(&k_trace_primary<4>));
 }
@@ -1561,14 +1626,17 @@ TracePlan trace_plan(const DevScene& sc) {
   const bool spill = P.lds_levels < P.levels;
   // nodelets staged in LDS: whatever the per-lane stacks leave of the workgroup's share of the CU's 160 KB at full occupancy
   // (32 waves per CU); 9 (root + one level) when the stacks alone do not fit, and occupancy then follows from the LDS
+  // 5-byte stack entries (PHX_STACK_PACKED): for the SPILL plan, when the pool's indices fit 24 bits
+  P.packed = (PHX_STACK_PACKED >= 2 || (PHX_STACK_PACKED == 1 && spill)) && sc.num_elems < (1u << 24) ? 1u : 0u;
+  auto stack_bytes = [&](uint32_t lv, uint32_t blk) { return P.packed ? (lv + ((lv + 3u) >> 2)) * blk * 4u : lv * blk * 8u; };
   auto plan = [&](uint32_t blk, uint32_t& ntop_out, uint32_t& lds_out) {  // -> workgroups per CU for this block size
     uint32_t ntop_req = E.ntop_env;
     if (!ntop_req) {
-      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = P.lds_levels * blk * 8u + 48u + (PHX_PERM_LUT ? 2048u : 0u);
+      const uint32_t share = 160u * 1024u / (2048u / blk), stacks = stack_bytes(P.lds_levels, blk) + 48u + (PHX_PERM_LUT ? 2048u : 0u);
       ntop_req = share > stacks + 9u * PHX_NODE_LDS_BYTES ? (share - stacks) / PHX_NODE_LDS_BYTES : 9u;
     }
     ntop_out = std::min(ntop_req, sc.num_elems);
-    lds_out = ntop_out * PHX_NODE_LDS_BYTES + P.lds_levels * blk * 8u + 48u + (PHX_PERM_LUT ? 2048u : 0u);
+    lds_out = ntop_out * PHX_NODE_LDS_BYTES + stack_bytes(P.lds_levels, blk) + 48u + (PHX_PERM_LUT ? 2048u : 0u);
     return std::min(160u * 1024u / lds_out, 2048u / blk);
   };
   // 1024-thread workgroups share one copy of the staged nodelets among 16 waves; a deep tree (levels >= 10: the stacks alone
@@ -1599,7 +1667,12 @@ void launch_trace(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
   auto go = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, g, b, lds, stream, sc, pb, q, sq, do_closest, do_shadow, E.refill, ntop, levels, E.min_chunks, E.target_chunks);
   };
-  if (P.lds_levels < P.levels) go(&k_trace<1024, true>);  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
+  if (P.lds_levels < P.levels) { if (P.packed) go(&k_trace<1024, true, true>); else go(&k_trace<1024, true>); }  // deep tree: 1024-thread workgroups, the stack's deep levels in HBM
+#if PHX_STACK_PACKED >= 2
+  else if (P.packed && block == 256) go(&k_trace<256, false, true>);
+  else if (P.packed && block == 512) go(&k_trace<512, false, true>);
+  else if (P.packed) go(&k_trace<1024, false, true>);
+#endif
   else if (block == 256) go(&k_trace<256>);
   else if (block == 512) go(&k_trace<512>);
   else go(&k_trace<1024>);
