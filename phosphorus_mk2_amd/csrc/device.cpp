@@ -804,7 +804,8 @@ int phx_device::run_frame() {
   stats.tri_pairs_pending = ds.tri_pairs_pending;
   stats.primary_packets = ds.primary_packets; stats.primary_fallbacks = ds.primary_fallbacks; stats.primary_node_tests = ds.primary_node_tests;
   stats.primary_tri_tests = ds.primary_tri_tests; stats.primary_tri_lanes_hit = ds.primary_tri_lanes_hit;
-  if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace / k_shade_g: " + std::to_string(ds.watchdog) + " wave(s) hit a watchdog (traversal iterations, or a wait on the shade kernel's append ring): the frame is incomplete");
+  if (ds.watchdog) return fail(PHX_ERR_DEVICE, "k_trace: " + std::to_string(ds.watchdog) + " wave(s) hit the iteration watchdog: the frame is incomplete");
+  if (ds.ring_watchdog) return fail(PHX_ERR_DEVICE, "k_shade_g: " + std::to_string(ds.ring_watchdog) + " wave(s) timed out waiting for a block of the append ring: the frame is incomplete");
   stats.trace_ms = stats.closest_ms + stats.shadow_ms + stats.primary_ms;
   stats.frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   static const bool host_timing = std::getenv("PHX_HOST_TIMING") != nullptr;

@@ -73,6 +73,7 @@ struct DevStats {
   // instrumented: pending (ray, triangle) pairs of the wave at its triangle-block executions — their sum, and executions by the number of
   // pairs: <= 8, <= 16, <= 24, <= 32, <= 48, <= 64, <= 96, more
   unsigned long long tri_pairs_pending, tri_pairs_hist[8];
+  unsigned long long ring_watchdog;    // k_shade_g waves whose wait on the append ring timed out (PHX_RING_SPINS): 0, or the frame is reported as failed
 };
 
 struct PassBuffers {

@@ -984,6 +984,12 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_PHASE_DECL
 #define PHX_PHASE(n)
 #endif
+#ifndef PHX_SHADE_PREFETCH_PERHIT
+#define PHX_SHADE_PREFETCH_PERHIT 0  /* the same two stages in the per-hit (glass) instantiations: measured worthless in round 5 (profiles/r05_c_shade_prefetch_glass_ab.log) */
+#endif
+#ifndef PHX_SCALAR_F_PERHIT
+#define PHX_SCALAR_F_PERHIT 0
+#endif
 #ifndef PHX_SCALAR_F
 #define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
 #endif
@@ -1043,97 +1049,69 @@ __device__ __forceinline__ void ring_flush(const float4* ring /* [NREC][2 x BLK]
     if (NREC == 3) g2[gb + k] = ring[4u * PHX_RING_BLK + first + k];
   }
 }
-// One wave's append to BOTH rings.  The steps of the two queues are interleaved so that their LDS round trips overlap: both reservations, then
-// both sets of records, then both commits — three waits on the LDS instead of six.
-struct RingSlot { unsigned long long mask; uint32_t n, pos, gen0, gen1; };
-__device__ __forceinline__ bool ring_wait(RingCtl* ctl, const RingSlot& t, unsigned long long* watchdog) {
-  // a block is written again only after its flush.  (A wait is rare: the block after next fills a whole round later than this one's flush
-  // starts.  Every wait is bounded — PHX_RING_SPINS sleeps of 64 clocks, ~30 ms — after which the wave counts itself in DevStats::watchdog,
-  // marks the workgroup's ring dead and drops its records: the frame is then reported as failed (device.cpp), as for k_trace's watchdog; no
-  // wave can spin for ever.)
+// The two queues are appended ONE AFTER THE OTHER, each completely (reserve, records, commit, flush if this wave completed a block) before the
+// next begins.  Interleaving them — both reservations, then both waits, both sets of records, both commits: three LDS round trips instead of
+// six — was built in round 6 and DEADLOCKED on the closed showroom: a wave then holds an uncommitted reservation in one ring while it waits
+// for a block of the other, and the two rings do not order the waves alike — inside a burst of eight waves (512 entries = the whole ring)
+// wave 1 can be ahead of wave 3 in ring A and behind it in ring B, each waiting for the block the other has not committed (state dumped at
+// the time-out: profiles/r06_g_ring_merged_deadlock.log).  One ring at a time, a wave waits only for LOWER positions of the SAME ring and
+// holds nothing else: a total order, no cycle.
+template <int NREC>
+__device__ __forceinline__ void ring_append(bool want, const float4& r0, const float4& r1, const float4& r2, RingCtl* ctl, float4* ring,
+                                            uint32_t* gcounter, float4* g0, float4* g1, float4* g2, unsigned long long* watchdog) {
+  constexpr uint32_t BLK = PHX_RING_BLK;
+  static_assert((BLK & (BLK - 1u)) == 0u && BLK >= 64u, "a wave's reservation spans at most two blocks");
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return;  // wave-uniform
+  const uint32_t lane = __lane_id(), n = (uint32_t)__popcll(mask);
+  uint32_t pos = 0;
+  if (lane == 0) pos = __hip_atomic_fetch_add(&ctl->head, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  pos = PHX_UNI(pos);
+  const uint32_t gen0 = pos / BLK, gen1 = (pos + n - 1u) / BLK;  // generation g lives in buffer g & 1; it is that buffer's (g >> 1)-th use
+  // (a wait is rare: the block after next fills a whole round later than this one's flush starts.  Every wait is bounded — PHX_RING_SPINS
+  // sleeps of 64 clocks, ~30 ms — after which the wave counts itself in DevStats::watchdog and goes on: the frame is then reported as failed
+  // (device.cpp), exactly as for k_trace's watchdog; no wave can spin for ever.)
   uint32_t spins = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const uint32_t gen = h ? t.gen1 : t.gen0;  // generation g lives in buffer g & 1; it is that buffer's (g >> 1)-th use
-    if (h && t.gen1 == t.gen0) break;
+    const uint32_t gen = h ? gen1 : gen0;
+    if (h && gen1 == gen0) break;
     while (PHX_UNI(__hip_atomic_load(&ctl->flushed[gen & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (gen >> 1)) {
       if (++spins > PHX_RING_SPINS || PHX_UNI(__hip_atomic_load(&ctl->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
-        if (__lane_id() == 0) { atomicAdd(watchdog, 1ull); __hip_atomic_store(&ctl->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        return false;
+        if (lane == 0) { atomicAdd(watchdog, 1ull); __hip_atomic_store(&ctl->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        return;
       }
       __builtin_amdgcn_s_sleep(1);
     }
   }
-  return true;
-}
-template <int NREC>
-__device__ __forceinline__ void ring_finish(RingCtl* ctl, const float4* ring, const RingSlot& t, uint32_t c0, uint32_t c1, uint32_t* gcounter, float4* g0, float4* g1, float4* g2) {
-  constexpr uint32_t BLK = PHX_RING_BLK;
-  const uint32_t n0 = min(t.n, (t.gen0 + 1u) * BLK - t.pos), n1 = t.n - n0;
+  asm volatile("" ::: "memory");
+  if (want) {
+    const uint32_t idx = (pos + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & (2u * BLK - 1u);
+    ring[idx] = r0; ring[2u * BLK + idx] = r1;
+    if (NREC == 3) ring[4u * BLK + idx] = r2;
+  }
+  PHX_LDS_ORDER();  // the records are in LDS before the commit
+  const uint32_t n0 = min(n, (gen0 + 1u) * BLK - pos), n1 = n - n0;
+  uint32_t c0 = 0, c1 = 0;
+  if (lane == 0) {
+    c0 = __hip_atomic_fetch_add(&ctl->committed[gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n1) c1 = __hip_atomic_fetch_add(&ctl->committed[gen1 & 1u], n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  c0 = PHX_UNI(c0); c1 = PHX_UNI(c1);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const uint32_t gen = h ? t.gen1 : t.gen0;
+    const uint32_t gen = h ? gen1 : gen0;
     if (h ? (n1 != 0u && c1 + n1 == BLK) : (c0 + n0 == BLK)) {  // this wave's commit completed the block: it flushes it
       asm volatile("" ::: "memory");
       ring_flush<NREC>(ring, (gen & 1u) * BLK, BLK, gcounter, g0, g1, g2);
       PHX_LDS_ORDER();  // the block has been read before it is handed back
-      if (__lane_id() == 0) {
+      if (lane == 0) {
         __hip_atomic_store(&ctl->committed[gen & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         PHX_LDS_ORDER();
         __hip_atomic_fetch_add(&ctl->flushed[gen & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
-}
-__device__ __forceinline__ void ring_append2(bool want_a, const float4& a0, const float4& a1, RingCtl* ctl_a, float4* ring_a, uint32_t* gcounter_a, float4* ga0, float4* ga1,
-                                             bool want_b, const float4& b0, const float4& b1, const float4& b2, RingCtl* ctl_b, float4* ring_b, uint32_t* gcounter_b, float4* gb0, float4* gb1, float4* gb2,
-                                             unsigned long long* watchdog) {
-  constexpr uint32_t BLK = PHX_RING_BLK;
-  static_assert((BLK & (BLK - 1u)) == 0u && BLK >= 64u, "a wave's reservation spans at most two blocks");
-  RingSlot A, B;
-  A.mask = __ballot(want_a); B.mask = __ballot(want_b);
-  A.n = (uint32_t)__popcll(A.mask); B.n = (uint32_t)__popcll(B.mask);
-  if ((A.mask | B.mask) == 0ull) return;  // wave-uniform
-  const uint32_t lane = __lane_id();
-  // ---- reserve: one ds_add_rtn per queue, both in flight
-  uint32_t pa = 0, pb = 0;
-  if (lane == 0) {
-    if (A.n) pa = __hip_atomic_fetch_add(&ctl_a->head, A.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (B.n) pb = __hip_atomic_fetch_add(&ctl_b->head, B.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  A.pos = PHX_UNI(pa); B.pos = PHX_UNI(pb);
-  A.gen0 = A.pos / BLK; A.gen1 = (A.pos + max(A.n, 1u) - 1u) / BLK;
-  B.gen0 = B.pos / BLK; B.gen1 = (B.pos + max(B.n, 1u) - 1u) / BLK;
-  const bool ok_a = A.n != 0u && ring_wait(ctl_a, A, watchdog), ok_b = B.n != 0u && ring_wait(ctl_b, B, watchdog);
-  asm volatile("" ::: "memory");
-  // ---- the records
-  const unsigned long long below = (1ull << lane) - 1ull;
-  if (ok_a && want_a) {
-    const uint32_t idx = (A.pos + (uint32_t)__popcll(A.mask & below)) & (2u * BLK - 1u);
-    ring_a[idx] = a0; ring_a[2u * BLK + idx] = a1;
-  }
-  if (ok_b && want_b) {
-    const uint32_t idx = (B.pos + (uint32_t)__popcll(B.mask & below)) & (2u * BLK - 1u);
-    ring_b[idx] = b0; ring_b[2u * BLK + idx] = b1; ring_b[4u * BLK + idx] = b2;
-  }
-  PHX_LDS_ORDER();  // the records are in LDS before the commits
-  // ---- commit: up to two counters per queue (a reservation may straddle two blocks), all in flight together
-  uint32_t ca0 = 0, ca1 = 0, cb0 = 0, cb1 = 0;
-  if (lane == 0) {
-    if (ok_a) {
-      const uint32_t n0 = min(A.n, (A.gen0 + 1u) * BLK - A.pos);
-      ca0 = __hip_atomic_fetch_add(&ctl_a->committed[A.gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (A.n != n0) ca1 = __hip_atomic_fetch_add(&ctl_a->committed[A.gen1 & 1u], A.n - n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (ok_b) {
-      const uint32_t n0 = min(B.n, (B.gen0 + 1u) * BLK - B.pos);
-      cb0 = __hip_atomic_fetch_add(&ctl_b->committed[B.gen0 & 1u], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (B.n != n0) cb1 = __hip_atomic_fetch_add(&ctl_b->committed[B.gen1 & 1u], B.n - n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-  ca0 = PHX_UNI(ca0); ca1 = PHX_UNI(ca1); cb0 = PHX_UNI(cb0); cb1 = PHX_UNI(cb1);
-  if (ok_b) ring_finish<3>(ctl_b, ring_b, B, cb0, cb1, gcounter_b, gb0, gb1, gb2);
-  if (ok_a) ring_finish<2>(ctl_a, ring_a, A, ca0, ca1, gcounter_a, ga0, ga1, nullptr);
 }
 template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
@@ -1251,7 +1229,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     };
     // (with per-hit closure weights — glass — either stage costs the kernel 16 B of scratch and buys nothing: 41.7-42.1 ms with, 41.9-42.2
     // without on the glass showroom, profiles/r05_c_shade_prefetch_glass_ab.log: those instantiations request where they consume)
-    constexpr bool STAGE1 = PHX_SHADE_PREFETCH >= 1 && !PERHIT, STAGE2 = PHX_SHADE_PREFETCH >= 2 && !PERHIT;
+    constexpr bool STAGE1 = PHX_SHADE_PREFETCH >= 1 && (!PERHIT || PHX_SHADE_PREFETCH_PERHIT >= 1), STAGE2 = PHX_SHADE_PREFETCH >= 2 && (!PERHIT || PHX_SHADE_PREFETCH_PERHIT >= 2);
     uint32_t k = DYN ? take_slice() : 0u, k_next = 0u;
     if constexpr (STAGE1) request_round(k);
     if constexpr (STAGE2) request_round_dependents();
@@ -1356,7 +1334,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           if (sdot(n, sh_d) >= 0.0f) {
             // li(), spt.hpp:212-255 — evaluated before the occlusion test; k_trace adds it if the ray is unoccluded
             v3 f(0.0f);
-            if constexpr (PHX_SCALAR_F && !PERHIT) {  // (with per-hit closure weights the uniform path costs the kernel 16 B of scratch)
+            if constexpr (PHX_SCALAR_F && (!PERHIT || PHX_SCALAR_F_PERHIT)) {  // (with per-hit closure weights the uniform path costs the kernel 16 B of scratch)
               PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, f = (bsdf_f<false, 8, PERHIT>(cm, n, fr, sh_d, wo)));
             } else {
               f = bsdf_f<false, 8, PERHIT>(sc.materials[mat], n, fr, sh_d, wo);
@@ -1420,10 +1398,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #if PHX_SHADE_RING
         {
           const v3 nxt_o = p + n * off;
-          ring_append2(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX),
-                       &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1],
-                       want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
-                       &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->watchdog);
+          ring_append<3>(want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
+                         &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->ring_watchdog);
+          ring_append<2>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+                         &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr, &pb.stats->ring_watchdog);
         }
         PHX_PHASE(4)  // the append: slot reservation, records to LDS, commit; for one wave in BLK / 64 rounds the flush of a block
         if constexpr (STAGE2) request_round_dependents();

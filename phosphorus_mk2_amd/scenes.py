@@ -388,16 +388,18 @@ def showroom(n, seed=5, width=1280, height=720, materials=None, closed=False):
     return SceneDesc(meshes, mats, CameraDesc(width, height, 1.9), name=f"showroom{n}{'_closed' if closed else ''}")
 
 
-def showroom_materials():
+def showroom_materials(per_hit_glass=True):
     """the 16 closure recipes of the BMW stand-in (closure_zoo() + four diffuse tints) plus Blender's glass node twice — sharp
-    (IoR 1.45) and frosted (IoR 1.33, roughness 0.2) — whose closure weights depend on the hit (k_shade_g<PERHIT>): 18 materials"""
-    return closure_zoo() + [diffuse(0.7, 0.2, 0.2), diffuse(0.2, 0.7, 0.2), diffuse(0.2, 0.2, 0.7), diffuse(0.5, 0.5, 0.1),
-                            glass(1.45, 0.0, (0.95, 0.98, 0.95), (1.0, 1.0, 1.0)), glass(1.33, 0.2, (0.9, 0.9, 1.0), (0.9, 0.9, 0.9))]
+    (IoR 1.45) and frosted (IoR 1.33, roughness 0.2) — whose closure weights depend on the hit (k_shade_g<PERHIT>): 18 materials.
+    per_hit_glass=False (A/B experiments only): the two glass materials as constant refraction + reflection mixes."""
+    z = closure_zoo()
+    g = [glass(1.45, 0.0, (0.95, 0.98, 0.95), (1.0, 1.0, 1.0)), glass(1.33, 0.2, (0.9, 0.9, 1.0), (0.9, 0.9, 0.9))] if per_hit_glass else [z[10], z[5]]
+    return z + [diffuse(0.7, 0.2, 0.2), diffuse(0.2, 0.7, 0.2), diffuse(0.2, 0.2, 0.7), diffuse(0.5, 0.5, 0.1)] + g
 
 
-def bmw_showroom(n=500_000, width=1920, height=1080):
+def bmw_showroom(n=500_000, width=1920, height=1080, per_hit_glass=True):
     """The mesh-geometry stand-in for BASELINE configs 3 / 5: the CLOSED showroom — connected surfaces, triangle sizes
     over three decades, no path escapes — with showroom_materials() on its 24 spheres.  multi_material_soup() stays the open, uniform one."""
-    s = showroom(n, width=width, height=height, materials=showroom_materials(), closed=True)
-    s.name = f"bmw_showroom{n}"
+    s = showroom(n, width=width, height=height, materials=showroom_materials(per_hit_glass), closed=True)
+    s.name = f"bmw_showroom{n}" + ("" if per_hit_glass else "_constant_glass")
     return s

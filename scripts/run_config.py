@@ -16,7 +16,7 @@ import numpy as np  # noqa: E402
 from phosphorus_mk2_amd import scenes, xpu  # noqa: E402
 
 p = argparse.ArgumentParser()
-p.add_argument("--scene", default="soup", choices=["soup", "zoo", "cornell", "showroom", "glassroom", "bmwroom"])
+p.add_argument("--scene", default="soup", choices=["soup", "zoo", "cornell", "showroom", "glassroom", "bmwroom", "bmwroom_cg"])
 p.add_argument("--triangles", type=int, default=100000)
 p.add_argument("--width", type=int, default=1280)
 p.add_argument("--height", type=int, default=720)
@@ -35,6 +35,8 @@ elif a.scene == "showroom":
     sc = scenes.showroom(a.triangles, width=a.width, height=a.height)
 elif a.scene == "glassroom":  # the showroom with Lambert, glass (per-hit Fresnel mix: k_shade_g<true>) and a glossy recipe on its spheres
     sc = scenes.showroom(a.triangles, width=a.width, height=a.height, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])
+elif a.scene == "bmwroom_cg":  # A/B only: the same room with the two glass materials as CONSTANT mixes (no per-hit weights: k_shade_g<false>)
+    sc = scenes.bmw_showroom(a.triangles, width=a.width, height=a.height, per_hit_glass=False)
 elif a.scene == "bmwroom":  # the closed showroom with the 16 recipes + sharp and frosted glass: the mesh-geometry stand-in for BASELINE configs 3 / 5
     sc = scenes.bmw_showroom(a.triangles, width=a.width, height=a.height)
 else:
