@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_SHADE_PREFETCH_PERHIT 0  /* the same two stages in the per-hit (glass) instantiations: measured worthless in round 5 (profiles/r05_c_shade_prefetch_glass_ab.log) */
 #endif
 #ifndef PHX_SCALAR_F_PERHIT
-#define PHX_SCALAR_F_PERHIT 0
+#define PHX_SCALAR_F_PERHIT 1  /* the per-hit (glass) instantiations read the recipe through the scalar cache too: with the ring append the kernel has the registers (127 / 123 VGPRs, no scratch; round 5: 16 B of scratch): closed showroom -4.4 %, glass showroom -2.9 % shade time (profiles/r06_i_perhit_knobs_ab.log) */
 #endif
 #ifndef PHX_SCALAR_F
 #define PHX_SCALAR_F 1  /* bsdf_f's lobe loop reads the recipe through the scalar cache: -0.6 % shade time, 128 -> 121 VGPRs */
@@ -1334,7 +1334,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           if (sdot(n, sh_d) >= 0.0f) {
             // li(), spt.hpp:212-255 — evaluated before the occlusion test; k_trace adds it if the ray is unoccluded
             v3 f(0.0f);
-            if constexpr (PHX_SCALAR_F && (!PERHIT || PHX_SCALAR_F_PERHIT)) {  // (with per-hit closure weights the uniform path costs the kernel 16 B of scratch)
+            if constexpr (PHX_SCALAR_F && (!PERHIT || PHX_SCALAR_F_PERHIT)) {
               PHX_FOR_EACH_MATERIAL_OF_THE_WAVE(mat, cm, f = (bsdf_f<false, 8, PERHIT>(cm, n, fr, sh_d, wo)));
             } else {
               f = bsdf_f<false, 8, PERHIT>(sc.materials[mat], n, fr, sh_d, wo);
