@@ -39,7 +39,9 @@ secondary records — goes to --full-json (default gpurun_out/bench_full.json). 
                (Soup(10 M), 3840x2160, 256 spp) on this one GPU, and on the declared stand-ins for BASELINE configs 3 and 5 (no BMW
                scene ships with the reference): the 16-recipe multi_material_soup(500 000) at 1920x1080 with 1024 spp and at
                3840x2160 with 4096 spp, both whole frames at BASELINE's sizes — those two carry a roofline of the general-closure
-               shade kernel, k_shade_g.
+               shade kernel, k_shade_g — and on the same two configurations with MESH geometry in a closed room
+               (scenes.bmw_showroom(500 000): 24 tessellated spheres, triangle sizes over three decades, the 16 recipes + sharp and
+               frosted glass, 7.3 rays per camera sample where the open soup has 1.9).
 """
 import argparse
 import glob
@@ -178,7 +180,7 @@ def workload_tag(kind, triangles, width, height, depth=9):
     if depth != 9:
         return None
     return {("soup", 100000, 1280, 720): "100k", ("soup", 1000000, 1280, 720): "1M", ("soup", 10000000, 3840, 2160): "c4",
-            ("zoo", 500000, 1920, 1080): "zoo", ("zoo", 500000, 3840, 2160): "zoo4k", ("room", 500000, 1920, 1080): "room"}.get((kind, triangles, width, height))
+            ("zoo", 500000, 1920, 1080): "zoo", ("zoo", 500000, 3840, 2160): "zoo4k", ("room", 500000, 1920, 1080): "room", ("room", 500000, 3840, 2160): "room"}.get((kind, triangles, width, height))
 
 
 def priced_source_hash():
@@ -603,7 +605,7 @@ def compact_line(full, full_path):
     else:
         out["cpu_baseline"] = None
     if full.get("secondary"):
-        out["secondary"] = [{"workload": s["workload"][:64], "value": _r(s["value"]), "ms_per_step": _r(s["ms_per_step"], 5),
+        out["secondary"] = [{"workload": s["workload"][:56], "value": _r(s["value"]), "ms_per_step": _r(s["ms_per_step"], 5),
                              "roofline": {"kernel": s["roofline"]["kernel"], "bound": s["roofline"]["bound"], "frac": _r(s["roofline"]["frac"], 4),
                                           **({"frac_by_counters": by_counters(s["roofline"])} if s["roofline"]["bound"] == "hbm" else {})}}
                             for s in full["secondary"]]
@@ -842,6 +844,9 @@ def main(argv=None):
                 sec.append(secondary_record(xpu, scenes, "BASELINE config 5 at its full size on the same stand-in scene: 3840x2160, 4096 spp, depth 9, the WHOLE frame on ONE GPU "
                                             "(34 G camera samples; one timed frame after a warm-up on every 32nd tile — two batches, one of them full-size — no host-film pass: the shading-bound regime, k_shade_g)",
                                             "zoo", 500000, 3840, 2160, 4096, args, cpu_seconds=0, steps=1, warmup=1, host_pass=False, warmup_shard=(0, 32)))
+                sec.append(secondary_record(xpu, scenes, "BASELINE config 5 at its full size on MESH geometry: bmw_showroom(500000), 3840x2160, 4096 spp, depth 9, the WHOLE frame on ONE GPU "
+                                            "(34 G camera samples, ~250 G rays; one timed frame after a warm-up on every 32nd tile, no host-film pass)",
+                                            "room", 500000, 3840, 2160, 4096, args, cpu_seconds=0, steps=1, warmup=1, host_pass=False, warmup_shard=(0, 32)))
                 out["secondary"] = sec
         else:
             out["cpu_baseline"] = None
