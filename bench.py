@@ -266,7 +266,7 @@ def capture_diagnostics(cap, src, kernel, units_in_capture):
     return D
 
 
-def roofline(acc, steps, work, tag, ref_visits):
+def roofline(acc, steps, work, tag, ref_visits, capture_is_this_frame=True):
     """k_trace.  acc: rays and k_trace ms summed over `steps` timed frames of THIS run; work: count_work() of one frame (instrumented
     build, same frame); tag: which committed capture holds this workload's counters.  The camera rays are k_trace_primary's (its own
     kernel, its own HIP events): rays, work and time here are k_trace's alone."""
@@ -287,7 +287,8 @@ def roofline(acc, steps, work, tag, ref_visits):
     roof["timing"] = ("HIP events on the device's own stream, ONE event between consecutive launches: a launch's time includes the few "
                       "microseconds since the previous kernel ended")
     cap, src = load_capture(tag)
-    D = capture_diagnostics(cap, src, "k_trace", rays_c + rays_s) if cap else None  # the captures render this same frame once
+    # (bytes per ray need the rays OF THE CAPTURE: the soup captures render this same frame once; the zoo / room captures render it at 256 spp)
+    D = capture_diagnostics(cap, src, "k_trace", (rays_c + rays_s) if capture_is_this_frame else None) if cap else None
     if work and "error" not in work and not peak:
         roof["frac_unavailable"] = peak_refused
     if work and "error" not in work and peak:
@@ -475,7 +476,7 @@ def secondary_record(xpu, scenes, name, kind, triangles, width, height, spp, arg
     if kind in ("zoo", "room"):
         rec["rays_per_camera_sample"] = (acc["closest"] + acc["shadow"]) / max(1, acc["camera"])
         rec["roofline"] = shade_roofline(acc, steps, st, tag)
-        rec["roofline_k_trace"] = roofline(acc, steps, None, tag, None)
+        rec["roofline_k_trace"] = roofline(acc, steps, None, tag, None, capture_is_this_frame=False)
         rec["primary"] = primary_record(acc, steps, None)
         return rec
     work = count_work(triangles, width, height, spp, "auto")
