@@ -31,7 +31,8 @@ static const uint32_t F_HIT = 1, F_MASKED = 2, F_SHADOW = 4, F_SPECULAR = 8;  //
 
 // numeric modes (SURVEY §7 hard part 2)
 inline int& scalar_default() { static int v = 0; return v; }
-inline int& debug_nonfinite() { static int v = 0; return v; }  // orc_set_debug_nonfinite: orender.cpp reports where a non-finite value enters a path
+inline int& debug_nonfinite() { static int v = 0; return v; }
+inline int* debug_pixel() { static int v[2] = {-1, -1}; return v; }  // orc_set_debug_pixel: orender.cpp prints the rays of this film pixel (diagnostic)  // orc_set_debug_nonfinite: orender.cpp reports where a non-finite value enters a path
 inline int& tie_default() { static int v = 0; return v; }     // process-wide default of modes_t::tie_lowest_prim (orc_set_tie_rule)  // process-wide default of modes_t::scalar (orc_set_scalar)
 struct modes_t {
   int rcp_approx = 0;   // 1: use the x86 RCPPS approximation where the reference does (this CPU only)
@@ -310,11 +311,20 @@ inline bool slab_literal(const node8_t& n, int c, const V3& o, const V3& ood, fl
   dist = nn;
   return nn <= ff;
 }
-// conservative variant: IEEE maxNum/minNum (NaN-ignoring) and both ends padded by 4 ulp, so a
-// rounding error in (b-o)*ood can never reject a box that contains a true hit point
+// conservative variant: IEEE maxNum/minNum (NaN-ignoring), both ends padded by 4 ulp — which covers the rounding of THIS arithmetic — and the
+// box itself inflated by 2^-18 x (|o|_1 + the box's largest coordinate), which covers the triangle test's: Moeller-Trumbore accepts u, v within a few
+// epsilon x |o - v0| / |edge| of the triangle's border, i.e. hit points up to a few 1e-7 x distance OUTSIDE the triangle (and its box).  Round 6 found
+// the 4-ulp form rejecting the leaf of a mirror-sphere facet whose edge a ray ran along: the restatement's traversal returned the neighbouring facet
+// (t 1.4738613) where testing ALL triangles — and the device — find t 1.4738580 (profiles/r06_l_oracle_slab_miss.json); 1 ray in 115 M.
+inline float slab_inflation(const node8_t& n, int c, const V3& o) {
+  float m = std::fabs(n.bounds[c]);
+  for (int k = 1; k < 6; ++k) m = std::fmax(m, std::fabs(n.bounds[c + 8 * k]));
+  return 3.814697265625e-6f * (std::fabs(o.x) + std::fabs(o.y) + std::fabs(o.z) + m);
+}
 inline bool slab_conservative(const node8_t& n, int c, const V3& o, const V3& ood, float d, float& dist) {
-  const float bminx = n.bounds[c], bminy = n.bounds[c + 8], bminz = n.bounds[c + 16];
-  const float bmaxx = n.bounds[c + 24], bmaxy = n.bounds[c + 32], bmaxz = n.bounds[c + 40];
+  const float pad = slab_inflation(n, c, o);
+  const float bminx = n.bounds[c] - pad, bminy = n.bounds[c + 8] - pad, bminz = n.bounds[c + 16] - pad;
+  const float bmaxx = n.bounds[c + 24] + pad, bmaxy = n.bounds[c + 32] + pad, bmaxz = n.bounds[c + 40] + pad;
   float nx = (ood.x >= 0.0f) ? bminx : bmaxx, fx = (ood.x >= 0.0f) ? bmaxx : bminx;
   float ny = (ood.y >= 0.0f) ? bminy : bmaxy, fy = (ood.y >= 0.0f) ? bmaxy : bminy;
   float nz = (ood.z >= 0.0f) ? bminz : bmaxz, fz = (ood.z >= 0.0f) ? bmaxz : bminz;
@@ -331,8 +341,18 @@ inline bool slab_conservative(const node8_t& n, int c, const V3& o, const V3& oo
 // ---- the same two tests on 8 lanes (AVX2) ------------------------------------------------------------------
 // One ray x the 8 child boxes of a node: bit i of the result = child i is hit, dist8[i] = its (unpadded) entry distance.
 inline unsigned slab8(const node8_t& n, const V3& o, const V3& ood, float d, bool literal, float* dist8) {
-  const __m256 minx = _mm256_loadu_ps(n.bounds), miny = _mm256_loadu_ps(n.bounds + 8), minz = _mm256_loadu_ps(n.bounds + 16);
-  const __m256 maxx = _mm256_loadu_ps(n.bounds + 24), maxy = _mm256_loadu_ps(n.bounds + 32), maxz = _mm256_loadu_ps(n.bounds + 40);
+  __m256 minx = _mm256_loadu_ps(n.bounds), miny = _mm256_loadu_ps(n.bounds + 8), minz = _mm256_loadu_ps(n.bounds + 16);
+  __m256 maxx = _mm256_loadu_ps(n.bounds + 24), maxy = _mm256_loadu_ps(n.bounds + 32), maxz = _mm256_loadu_ps(n.bounds + 40);
+  if (!literal) {  // the conservative form inflates every child box (slab_inflation above, the same operations per lane)
+    const __m256 am = _mm256_castsi256_ps(_mm256_set1_epi32(0x7fffffff));
+    __m256 m = _mm256_and_ps(minx, am);
+    m = _mm256_max_ps(m, _mm256_and_ps(miny, am)); m = _mm256_max_ps(m, _mm256_and_ps(minz, am));
+    m = _mm256_max_ps(m, _mm256_and_ps(maxx, am)); m = _mm256_max_ps(m, _mm256_and_ps(maxy, am)); m = _mm256_max_ps(m, _mm256_and_ps(maxz, am));
+    const float ro = std::fabs(o.x) + std::fabs(o.y) + std::fabs(o.z);
+    const __m256 pad = _mm256_mul_ps(_mm256_set1_ps(3.814697265625e-6f), _mm256_add_ps(_mm256_set1_ps(ro), m));
+    minx = _mm256_sub_ps(minx, pad); miny = _mm256_sub_ps(miny, pad); minz = _mm256_sub_ps(minz, pad);
+    maxx = _mm256_add_ps(maxx, pad); maxy = _mm256_add_ps(maxy, pad); maxz = _mm256_add_ps(maxz, pad);
+  }
   const bool gx = ood.x >= 0.0f, gy = ood.y >= 0.0f, gz = ood.z >= 0.0f;
   const __m256 ox = _mm256_set1_ps(o.x), oy = _mm256_set1_ps(o.y), oz = _mm256_set1_ps(o.z);
   const __m256 rx = _mm256_set1_ps(ood.x), ry = _mm256_set1_ps(ood.y), rz = _mm256_set1_ps(ood.z);

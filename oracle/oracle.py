@@ -115,6 +115,11 @@ def set_debug_nonfinite(on):
     load().orc_set_debug_nonfinite(1 if on else 0)
 
 
+def set_debug_pixel(x, y):
+    """diagnostic: the renderer prints to stderr the shadow ray of every step of every sample of film pixel (x, y) and its occlusion (x < 0: off)"""
+    load().orc_set_debug_pixel(int(x), int(y))
+
+
 def probe_soup(n):
     """(n, 9) float32 triangles of the soup the survey's probe rendered with the real reference:
     std::mt19937(1234) + std::uniform_real_distribution<float>(-1, 1), 12 draws per triangle."""

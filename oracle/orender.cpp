@@ -304,6 +304,7 @@ struct tile_renderer_t {
       rays.d[i] = d; rays.flags[i] = flags;
       st.pdf[i] = lpdf[i];
     }
+    if (dbg_slot >= 0) { dbg_tmax.assign(upto, 0.0f); for (uint32_t i = 0; i < upto; ++i) dbg_tmax[i] = rays.d[i]; }  // the shadow trace overwrites d with the hit distance
   }
 
   // spt::integrator_t::li, spt.hpp:212-255
@@ -358,6 +359,9 @@ struct tile_renderer_t {
     else { const uint32_t b = (st.depth[index] - 1u) * DIMS_PER_STEP; s = V2(draw_f32(key, b + DIM_BSDF_U), draw_f32(key, b + DIM_BSDF_V)); }
     uint32_t flags; float pdf; V3 sampled;
     const V3 f = out.bsdf[from].sample(s, wi, sampled, pdf, flags);
+    if (dbg_slot >= 0 && (int)index == dbg_slot)
+      std::fprintf(stderr, "orc dbg sample: sample %u depth %u material %d n %.9g %.9g %.9g view %.9g %.9g %.9g u %.9g %.9g -> f %.9g %.9g %.9g pdf %.9g dir %.9g %.9g %.9g flags 0x%x\n", cur_sample, st.depth[index], (int)out.material[from],
+                   n.x, n.y, n.z, wi.x, wi.y, wi.z, s.x, s.y, f.x, f.y, f.z, pdf, sampled.x, sampled.y, sampled.z, flags);
     if ((f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) || pdf == 0.0f) return false;
     const float weight = n.dot(sampled);
     st.beta[index] = beta * (f * (std::fabs(weight) / pdf));
@@ -381,6 +385,10 @@ struct tile_renderer_t {
     for (uint32_t i = 0; i < num; ++i) {
       const uint32_t index = active_index[i];
       V3 o = st.r[index];
+      if (dbg_slot >= 0 && (int)index == dbg_slot)  // diagnostic hook (orc_set_debug_pixel): this pixel's shadow ray of the step and what the trace said
+        std::fprintf(stderr, "orc dbg pixel: sample %u depth %u hit %d shadow o %.9g %.9g %.9g d %.9g %.9g %.9g tmax %.9g flags 0x%x occluded %d material %d n %.9g %.9g %.9g view %.9g %.9g %.9g beta %.9g %.9g %.9g\n", cur_sample, st.depth[index],
+                     (int)out.is_hit(i), rays.px[i], rays.py[i], rays.pz[i], rays.wx[i], rays.wy[i], rays.wz[i], dbg_tmax[i < dbg_tmax.size() ? i : 0], rays.flags[i], (int)rays.is_occluded(i), (int)out.material[i],
+                     out.n[i].x, out.n[i].y, out.n[i].z, out.wi[i].x, out.wi[i].y, out.wi[i].z, st.beta[index].x, st.beta[index].y, st.beta[index].z);
       if (out.is_hit(i)) {
         if (st.depth[index] == 0 || out.is_specular(i)) o += st.beta[index] * out.e[i];
         if (!rays.is_occluded(i)) o += st.beta[index] * li(out, i);
@@ -417,8 +425,14 @@ struct tile_renderer_t {
     if ((++calls & 1023) == 0) std::fprintf(stderr, "orc profile: trace %.3f shade %.3f nee %.3f shadow-trace %.3f integrate %.3f s\n", acc[0], acc[1], acc[2], acc[3], acc[4]);
   }
 
+  int dbg_slot = -1;             // diagnostic: slot of the film pixel of orc_set_debug_pixel inside the current tile, -1 = none
+  std::vector<float> dbg_tmax;
   void render_tile(const phx_tile& tile, float* film, float* normals) {  // cpu.cpp:156-205
     cur_tile = tile;
+    {
+      const int* dp = debug_pixel();
+      dbg_slot = (dp[0] >= (int)tile.x && dp[0] < (int)(tile.x + tile.w) && dp[1] >= (int)tile.y && dp[1] < (int)(tile.y + tile.h)) ? (dp[1] - (int)tile.y) * (int)tile.w + (dp[0] - (int)tile.x) : -1;
+    }
     rays = rays_t(); rays.resize(STREAM);            // new(allocator) ray_t<>() value-initialises
     primary.resize(STREAM); hits.resize(STREAM);
     const uint32_t spp = O.opt.samples_per_pixel, pps = O.opt.paths_per_sample;
@@ -471,6 +485,8 @@ void orc_set_scalar(int on) { scalar_default() = on; }
 void orc_set_tie_rule(int lowest_prim) { tie_default() = lowest_prim; }
 // diagnostic: 1 = print to stderr where a non-finite value enters a path (li() or the throughput update); results are unchanged
 void orc_set_debug_nonfinite(int on) { debug_nonfinite() = on; }
+// diagnostic: print, for every step of every sample of film pixel (x, y), its shadow ray and whether the trace found it occluded (x < 0: off)
+void orc_set_debug_pixel(int x, int y) { debug_pixel()[0] = x; debug_pixel()[1] = y; }
 
 void* orc_create(const phx_scene* scene, const phx_options* options) {
   oracle_t* o = new oracle_t();

@@ -8,12 +8,14 @@ from phosphorus_mk2_amd import scenes, xpu
 from oracle import oracle as orc
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-what = sys.argv[2] if len(sys.argv) > 2 else "100000"   # triangle count of the soup, "cornell" (BASELINE config #1: 256x256), "zoo:N" (BMW stand-in, 1920x1080), "showroom:N"
+what = sys.argv[2] if len(sys.argv) > 2 else "100000"   # triangle count of the soup, "cornell" (BASELINE config #1: 256x256), "zoo:N" (BMW stand-in, 1920x1080), "showroom:N", "bmwroom:N"
 builder = sys.argv[3] if len(sys.argv) > 3 else "auto"
 if what == "cornell":
     sc = scenes.cornell(256, 256)
 elif what.startswith("zoo:"):
     sc = scenes.multi_material_soup(int(what[4:]), width=1920, height=1080)
+elif what.startswith("bmwroom:"):  # the closed mesh room with the 16 recipes + sharp and frosted glass (BASELINE configs 3 / 5 on mesh geometry), 1280x720
+    sc = scenes.bmw_showroom(int(what[8:]), width=1280, height=720)
 elif what.startswith("showroom:"):
     sc = scenes.showroom(int(what[9:]), width=1280, height=720, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])
 else:

@@ -114,3 +114,31 @@ def test_simd_and_scalar_restatements_agree(orc, scene_name):
             assert bits_equal(a[2][k], b[2][k])
         assert np.array_equal(a[2]["prim"], b[2]["prim"]) and np.array_equal(a[3]["hit"], b[3]["hit"])
         assert a[2]["node_visits"] == b[2]["node_visits"] and a[2]["packet_visits"] == b[2]["packet_visits"]
+
+
+def test_traversal_finds_the_hit_on_a_facet_edge_that_brute_force_finds(orc):
+    """Round 6: ONE pixel of the closed showroom differed between device and oracle (L2 5e-5).  Replaying the pixel's rays stage by stage
+    (scripts/pixel_replay_probe.py, profiles/r06_l_oracle_slab_miss.json) showed the DEVICE agreeing with the oracle's brute-force test of all
+    triangles (t 1.4738580, primitive 427989) and the oracle's BVH traversal returning the neighbouring facet of the mirror sphere (t 1.4738613):
+    the ray runs along the facets' shared edge, Moeller-Trumbore accepts it a few 1e-7 outside the nearer facet, and the "conservative" slab test —
+    padded for ITS rounding only — rejected that facet's leaf.  The slab test now inflates the boxes for the triangle test's tolerance too
+    (oracle/obvh.h: slab_inflation); this ray pins it, in both restatements."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.bmw_showroom(500_000, width=64, height=64)
+    o = np.array([[1.9998998641967773, -0.019932806491851807, -4.015493392944336]], np.float32)
+    d = np.array([[-0.40463271737098694, 0.10292842984199524, 0.9086683988571167]], np.float32)
+    tm = np.array([np.finfo(np.float32).max], np.float32)
+    orc.set_tie_rule(1)
+    try:
+        O = orc.Oracle(sc, spp=1)
+        b = O.trace(o, d, tm, brute=True)
+        for scalar in (0, 1):
+            orc.set_scalar(scalar)
+            try:
+                t = O.trace(o, d, tm)
+            finally:
+                orc.set_scalar(0)
+            assert int(t["prim"][0]) == int(b["prim"][0]) == 427989 and bits_equal(t["t"], b["t"]), (scalar, t["t"], t["prim"], b["t"], b["prim"])
+        O.close()
+    finally:
+        orc.set_tie_rule(0)
