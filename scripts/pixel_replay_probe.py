@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One pixel differs between device and oracle: which of its rays?  Run ON the GPU box.
+"""One pixel differs between device and oracle: which of its rays, which closure evaluation?  Run ON the GPU box.
     python scripts/pixel_replay_probe.py bmwroom:500000 1280 720 32 237 191 [seed]
 The oracle renders the pixel's strip with its diagnostic hook on (oracle.set_debug_pixel) and prints the shadow ray of every step of every
 sample with the occlusion ITS traversal found; the same rays then go through the device's stage-level trace (phx_dev_trace, any-hit), the
