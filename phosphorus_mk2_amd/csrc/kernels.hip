@@ -1440,7 +1440,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   if (threadIdx.x < 128u) {
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t head = ring_ctl[w].head, left = head & (PHX_RING_BLK - 1u), first = ((head / PHX_RING_BLK) & 1u) * PHX_RING_BLK;
-    if (left) {
+    // (a ring that timed out is NOT flushed: a wave that gave up has reserved slots it never wrote, and whatever LDS held there — records of two
+    // blocks ago, or nothing at all — must not reach a queue, where a path id is an index.  The frame is reported as failed anyway.  The
+    // ring-watchdog twin library faulted the GPU on exactly this until the guard was added: tests/test_gpu_parity.py::test_append_ring_timeout_…)
+    if (left && !ring_ctl[w].dead) {
       if (w == 0u) ring_flush<2>(ring_a, first, left, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr);
       else ring_flush<3>(ring_b, first, left, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc);
     }

@@ -990,6 +990,37 @@ def test_watchdog_fails_the_frame_instead_of_hanging(xpu, orc):
     assert st["rays_closest"] == ost["rays_closest"] and bits_equal(film[..., :3], ref[..., :3])
 
 
+def test_append_ring_timeout_fails_the_frame_instead_of_hanging(xpu, orc):
+    """k_shade_g's waves wait for a block of the workgroup's append ring only a bounded time (PHX_RING_SPINS): a wave that gives up raises
+    DevStats::ring_watchdog, the workgroup drops its later records, and phx_dev_join reports the frame as FAILED (PHX_ERR_DEVICE) — never a hang, never a film
+    with holes handed over as good (round 6: this is how an append variant that could deadlock showed up as a log line, profiles/r06_g_ring_merged_deadlock.log).
+    libphx_hip_ringwd.so is the same library with a patience of zero and a ring of 2 x 64 entries (__graft_entry__.build): any busy workgroup trips it.
+    Afterwards the device is intact: the product library renders the oracle's film of the same scene."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    from phosphorus_mk2_amd import scenes
+    wd = os.path.join(ROOT, "phosphorus_mk2_amd", "libphx_hip_ringwd.so")
+    assert os.path.exists(wd), "build() makes the ring-watchdog twin"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from phosphorus_mk2_amd import scenes, xpu\n"
+            "try:\n"
+            "    xpu.render(scenes.multi_material_soup(3000, width=128, height=128), spp=16, seed=2)\n"
+            "    print('RENDERED')\n"
+            "except xpu.DeviceError as e:\n"
+            "    print('FAILED:', e)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, PHX_LIB=wd))
+    assert r.returncode == 0 and "FAILED:" in r.stdout and "append ring" in r.stdout and "RENDERED" not in r.stdout, (r.stdout, r.stderr[-500:])
+    sc = scenes.multi_material_soup(3000, width=128, height=128)
+    film, st = xpu.render(sc, spp=16, seed=2)
+    orc.set_tie_rule(1)
+    try:
+        ref, ost = orc.Oracle(sc, spp=16, pps=1, depth=9).render(rng=orc.RNG_COUNTER, seed=2, threads=8)
+    finally:
+        orc.set_tie_rule(0)
+    fin = np.isfinite(ref[..., :3]).all(-1)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and bits_equal(film[..., :3][fin], ref[..., :3][fin])
+
+
 def test_frames_without_kernel_timing_render_the_same_film(xpu):
     """PHX_KERNEL_TIMING=0 (a probe knob, read once per process): no HIP events between the launches — phx_stats carries no kernel times,
     the film and the ray counts are the ones of a timed frame"""
