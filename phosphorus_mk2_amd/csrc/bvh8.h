@@ -86,6 +86,26 @@ PHX_HD void node_origin_decode(uint32_t w0, uint32_t w1, const SceneGrid& g, flo
   pz = fmaf((float)iz, g.cell[2], g.lo[2]);
   valid = (w1 >> 22) & 0xffu;
 }
+// How far outside a triangle the reference's Moeller-Trumbore (mt_intersect below) can still report a hit: u, v and u + v are tested after
+// fp32 rounding of sums that cancel — t = o - v0 of the scene's size times edge vectors of the triangle's — and a ray that misses a 0.01-wide
+// facet by 3.4e-6 (exact arithmetic: u + v = 1.00038, 38 x epsilon x the distance) was accepted in round 6; a box that holds the triangle exactly
+// then culls a hit the triangle test would report, and the closest hit depends on the tree (one pixel of 2 M x 256 samples differed between the
+// device-built and the host-built tree of the closed showroom; profiles/r06_m_*).  Both builders therefore inflate every TRIANGLE's box by
+// delta = 2^-18 x (largest extent of the scene + largest coordinate) — 64 x epsilon x the scene's size, ten times the miss that was seen — before
+// anything else; node boxes are unions of those.  (No finite delta is a proof: the tolerance grows without bound for grazing rays and slivers.  It is a
+// margin, sized on the one violation 10^11 rays produced; k_trace pays +0.3 ... +0.8 % for it, profiles/r06_m_tri_box_inflation_ab.log.)
+#ifndef PHX_TRI_BOX_INFLATE
+#define PHX_TRI_BOX_INFLATE 1  /* 0: A/B only (the trees of rounds 1-5) */
+#endif
+PHX_HD float tri_box_inflation(const float* lo, const float* hi) {
+  if (!PHX_TRI_BOX_INFLATE) return 0.0f;
+  float ext = 0.0f, mag = 0.0f;
+  for (int a = 0; a < 3; ++a) {
+    ext = fmaxf(ext, hi[a] - lo[a]);
+    mag = fmaxf(mag, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+  }
+  return (ext + mag) * 3.814697265625e-6f;  // 2^-18
+}
 // largest grid index whose decoded coordinate does not exceed x (0 when x lies below the grid)
 PHX_HD uint32_t grid_index_below(float x, float lo, float cell) {
   double t = floor(((double)x - (double)lo) / (double)cell);

@@ -197,6 +197,11 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
     scene.grow(b);
     for (int a = 0; a < 3; ++a) cen[3 * (size_t)i + a] = 0.5f * (b.lo[a] + b.hi[a]);
   }
+  {  // every triangle's box grows by the triangle test's own tolerance (bvh8.h: tri_box_inflation); the scene's with them
+    const float delta = tri_box_inflation(scene.lo, scene.hi);
+    for (uint32_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { pbox[i].lo[a] -= delta; pbox[i].hi[a] += delta; }
+    for (int a = 0; a < 3; ++a) { scene.lo[a] -= delta; scene.hi[a] += delta; }
+  }
   out.grid = make_scene_grid(scene.lo, scene.hi);
   Builder2 B;
   B.pbox = pbox.data(); B.centroid = cen.data();

@@ -186,9 +186,16 @@ __device__ __forceinline__ Box6 load_box(const Box6* src) {
   return b;
 }
 
-__global__ void __launch_bounds__(GB) k_leaf_boxes(const Box6* __restrict__ pbox, const uint32_t* __restrict__ sorted, int n, Box6* __restrict__ nbox) {
+// the leaves' boxes: a triangle's box grown by the triangle test's own tolerance (bvh8.h: tri_box_inflation, from the scene's geometry bounds in cb[6..11])
+__global__ void __launch_bounds__(GB) k_leaf_boxes(const Box6* __restrict__ pbox, const uint32_t* __restrict__ sorted, int n, Box6* __restrict__ nbox, const uint32_t* __restrict__ cb) {
   const int k = blockIdx.x * GB + threadIdx.x;
-  if (k < n) nbox[n - 1 + k] = pbox[sorted[k]];
+  if (k >= n) return;
+  float glo[3], ghi[3];
+  for (int a = 0; a < 3; ++a) { glo[a] = ord2f(cb[6 + a]); ghi[a] = ord2f(cb[9 + a]); }
+  const float delta = tri_box_inflation(glo, ghi);
+  Box6 b = pbox[sorted[k]];
+  for (int a = 0; a < 3; ++a) { b.lo[a] -= delta; b.hi[a] += delta; }
+  nbox[n - 1 + k] = b;
 }
 // boxes of the n-1 inner nodes (the leaves' are there: k_leaf_boxes); node ids as above.  flags[] must be zero.
 __global__ void __launch_bounds__(GB) k_fit(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
@@ -507,7 +514,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   void* temp = dalloc(temp_bytes);
   if (!temp) { std::snprintf(err, errlen, "hipMalloc failed (sort scratch)"); cleanup(); return BVH_GPU_RECOVERABLE; }
   HCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys2, vals, sorted, (size_t)n, 0, 63, stream));
-  hipLaunchKernelGGL(k_leaf_boxes, g, b, 0, stream, pbox, sorted, (int)n, nbox);
+  hipLaunchKernelGGL(k_leaf_boxes, g, b, 0, stream, pbox, sorted, (int)n, nbox, cb);
   // (The binary tree is Karras' radix tree over the extended Morton keys.  PLOC — bottom-up merging of the clusters whose union has the
   // smallest surface area, radius 16 — was built in its place and measured: lower modelled cost (-1 % soups, -9 % showroom) but 15 %
   // MORE node visits and 24 % more triangle tests per ray on the soups, k_trace +17 ... +35 %, +1 ... +2 % on the showroom: merged
@@ -525,6 +532,10 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   HCHK(hipStreamSynchronize(stream));
   float glo[3], ghi[3];
   for (int a = 0; a < 3; ++a) { glo[a] = ord2f(h_cb[6 + a]); ghi[a] = ord2f(h_cb[9 + a]); }
+  {  // the leaves' boxes were grown by delta (k_leaf_boxes): so is the grid that has to hold them
+    const float delta = tri_box_inflation(glo, ghi);
+    for (int a = 0; a < 3; ++a) { glo[a] -= delta; ghi[a] += delta; }
+  }
   const SceneGrid grid = make_scene_grid(glo, ghi);
 
   // output pool: n triangle records + at most n - 1 nodelets (every nodelet has at least two children)

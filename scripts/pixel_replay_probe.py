@@ -51,13 +51,13 @@ o = np.array([[float(r[3]), float(r[4]), float(r[5])] for r in rows], np.float32
 d = np.array([[float(r[6]), float(r[7]), float(r[8])] for r in rows], np.float32)
 tm = np.array([float(r[9]) for r in rows], np.float32)
 occ_render = np.array([int(r[11]) for r in rows], bool)
-dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=9))
+dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=9, bvh_builder=os.environ.get("PHX_PROBE_BUILDER", "auto")))
 dev.preprocess(sc)
 g = dev.trace(o, d, tm, shadow=True)
 dev.close()
 t = O.trace(o, d, tm, shadow=True)
 b = O.trace(o, d, tm, shadow=True, brute=True)
-out = {"scene": sc.name, "pixel": [px, py], "spp": spp, "shadow_rays": len(rows), "oracle_trace_equals_its_render": bool(np.array_equal(t["hit"], occ_render)),
+out = {"scene": sc.name, "builder": os.environ.get("PHX_PROBE_BUILDER", "auto"), "pixel": [px, py], "spp": spp, "shadow_rays": len(rows), "oracle_trace_equals_its_render": bool(np.array_equal(t["hit"], occ_render)),
        "device_vs_oracle_mismatches": int((g["hit"] != t["hit"]).sum()), "device_vs_brute_mismatches": int((g["hit"] != b["hit"]).sum()),
        "oracle_vs_brute_mismatches": int((t["hit"] != b["hit"]).sum()), "rays": []}
 for i in np.argwhere((g["hit"] != t["hit"]) | (g["hit"] != b["hit"]) | (t["hit"] != occ_render)).ravel():
@@ -66,7 +66,7 @@ for i in np.argwhere((g["hit"] != t["hit"]) | (g["hit"] != b["hit"]) | (t["hit"]
                         "oracle_render_occluded": bool(occ_render[i]), "flags_after_the_render's_trace": rows[i][10], "material_of_the_shaded_hit": int(rows[i][12]), "device_occluded": bool(g["hit"][i]), "oracle_traversal_occluded": bool(t["hit"][i]), "oracle_brute_force_occluded": bool(b["hit"][i]),
                         "device_t": float(g["t"][i]), "brute_t": float(b["t"][i]), "device_prim": int(g["prim"][i]), "brute_prim": int(b["prim"][i])})
 # the closure evaluations of the same steps, replayed on both sides: li()'s f (light direction = the shadow ray's) and the sampled continuation
-dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=9))
+dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=spp, paths_per_sample=1, path_depth=9, bvh_builder=os.environ.get("PHX_PROBE_BUILDER", "auto")))
 dev.preprocess(sc)
 out["f_mismatches"], out["sample_mismatches"] = [], []
 for mat in sorted({int(r[12]) for r in rows}):

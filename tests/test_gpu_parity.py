@@ -832,6 +832,26 @@ def test_full_size_frame_with_a_lit_edge_band(xpu, orc):
     assert (film[704:, 640:, :3].sum(-1) > 0).mean() > 0.08 and (film[:, 1248:, :3].sum(-1) > 0).mean() > 0.2  # band and last column are lit
 
 
+def test_host_and_device_trees_give_the_same_film_in_the_closed_room(xpu):
+    """Results must not depend on the tree.  Round 6 found the ONE case in ~1e11 rays where they did: pixel (1685, 541) of this very frame differed
+    between the device-built and the host-built tree — a ray along a facet edge that Moeller-Trumbore accepts 3.4e-6 outside the facet (38 x epsilon x
+    the distance), where the host tree's exact child box culled it.  Both builders now grow every triangle's box by the test's own tolerance
+    (bvh8.h: tri_box_inflation); this frame — 2 G rays per tree — pins it."""
+    from phosphorus_mk2_amd import scenes
+    sc = scenes.bmw_showroom(500_000, width=1920, height=1080)
+    films, stats = {}, {}
+    for b in ("device", "host"):
+        films[b], stats[b] = xpu.render(sc, spp=256, seed=1, native_sink=True, bvh_builder=b)
+    for k in ("rays_closest", "rays_shadow", "rays_masked"):
+        assert stats["device"][k] == stats["host"][k], k
+    assert stats["device"]["bvh_built_on_device"] == 1 and stats["host"]["bvh_built_on_device"] == 0
+    a, c = films["device"][..., :3], films["host"][..., :3]
+    fin = np.isfinite(a).all(-1)
+    assert np.array_equal(fin, np.isfinite(c).all(-1)) and fin.mean() > 0.99999
+    assert int((a[fin].view(np.uint32) != c[fin].view(np.uint32)).any(-1).sum()) == 0
+    assert bits_equal(a[541, 1685], c[541, 1685])  # the pixel that differed
+
+
 def test_closed_room_whole_frame_matches_oracle(xpu, orc):
     """scenes.bmw_showroom(500 000) — closed room, mesh spheres, 16 recipes + glass, 7 rays per camera sample, a deep tree (the 5-byte-stack plan of
     k_trace, the per-hit kernels of k_shade_g) — whole 1280x720 frame at 32 spp against the oracle: counts and every pixel, bit for bit.  (Round 6:
