@@ -9,7 +9,8 @@ from phosphorus_mk2_amd import scenes, xpu
 what, W, H, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 kind, n = what.split(":")
 sc = {"bmwroom": lambda: scenes.bmw_showroom(int(n), width=W, height=H), "zoo": lambda: scenes.multi_material_soup(int(n), width=W, height=H),
-      "soup": lambda: scenes.soup(int(n), width=W, height=H)}[kind]()
+      "soup": lambda: scenes.soup(int(n), width=W, height=H), "cornell": lambda: scenes.cornell(W, H),
+      "glassroom": lambda: scenes.showroom(int(n), width=W, height=H, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])}[kind]()
 films, stats = {}, {}
 for b in ("device", "host"):
     films[b], stats[b] = xpu.render(sc, spp=spp, pps=1, depth=9, seed=1, native_sink=True, bvh_builder=b)
