@@ -128,8 +128,9 @@ typedef struct phx_mesh {
 } phx_mesh;
 enum { PHX_MESH_UV_PER_VERTEX = 1, PHX_MESH_NORMALS_PER_VERTEX = 2 }; /* mesh_t::flags_t, src/mesh.hpp:20-23 */
 
-/* camera_t, src/entities/camera.hpp:10-39.  Pinhole only (aperture_radius must be 0: the
- * reference thin-lens path is broken, SURVEY A-21). */
+/* camera_t, src/entities/camera.hpp:10-39.  aperture_radius == 0: pinhole (camera_t::is_pinhole); otherwise the thin lens of
+ * src/kernels/cpu/camera.hpp:140-147 with the disc mapping of src/math/simd/sampling.hpp:8-32 as the reference wrote it (SURVEY A-21:
+ * raw samples, swapped select) and focal_distance the distance of the plane in focus.  Both must be finite. */
 typedef struct phx_camera {
   float    to_world[16]; /* Imath::M44f x[i][j], row-vector convention v' = v * M */
   float    fov;

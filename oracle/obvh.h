@@ -440,12 +440,17 @@ struct stream_tracer_t {
     tasks.clear();
     // 1/dir is a function of the ray alone: computed once here instead of at every node visit (same values)
     inv_dir.resize(num);
+    uint64_t not_finite = 0;
     for (uint32_t i = 0; i < num; ++i) if (!R.is_masked(i)) {
+      const V3 w = R.wi(i), o = R.p(i);
+      // A NaN ray (the thin lens with a zero lens sample, camera.hpp:140-147) hits nothing HERE.  In the reference it passes every box test
+      // (simd max / min return their second operand on NaN: n = 0, f = d, aabb.hpp:56-59) — the empty child slots too, whose offset 0 is
+      // the root: the stream re-enters the root for ever.  A stated deviation: the ray is counted and left alone.
+      if (!std::isfinite((o.x + o.y + o.z) + (w.x + w.y + w.z))) { ++not_finite; continue; }
       lanes[0].push_back(i);
-      const V3 w = R.wi(i);
       inv_dir[i] = modes.rcp_approx ? V3(rcp_approx(w.x), rcp_approx(w.y), rcp_approx(w.z)) : V3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
     }
-    ctr.rays += lanes[0].size();
+    ctr.rays += lanes[0].size() + not_finite;
     if (lanes[0].empty() || !bvh->has_root) return;
     tasks.push_back(task_t{0, (uint32_t)lanes[0].size(), 0, 0, 0});
     std::vector<uint32_t> todo;

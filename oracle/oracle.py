@@ -61,6 +61,7 @@ def load(libm=False):
     lib.orc_render.argtypes = [vp, C.POINTER(RenderArgs), f32p, f32p, C.POINTER(OStats)]; lib.orc_render.restype = C.c_int
     lib.orc_bench.argtypes = [vp, C.POINTER(RenderArgs), C.c_double, f32p, C.POINTER(OStats), u32p]; lib.orc_bench.restype = C.c_int
     lib.orc_jitter_table.argtypes = [C.c_uint64, C.c_uint32, f32p]; lib.orc_jitter_table.restype = C.c_int
+    lib.orc_camera_rays.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(abi.Tile), C.c_uint32, f32p, f32p]; lib.orc_camera_rays.restype = C.c_int
     lib.orc_trace.argtypes = [vp, C.c_uint32, f32p, f32p, f32p, u32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, u32p, u32p,
                               C.POINTER(C.c_uint64)]
     lib.orc_trace.restype = C.c_int
@@ -156,6 +157,15 @@ class Oracle:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.lib.orc_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"nodes": a.value, "packets": b.value, "triangles": c.value}
+
+    def camera_rays(self, tile, sample, seed=1):
+        """origins and directions [w * h, 3] of the camera rays of one tile (x, y, w, h) at one sample index (counter RNG)"""
+        t = abi.Tile(*tile)
+        o = np.zeros((tile[2] * tile[3], 3), np.float32); d = np.zeros_like(o)
+        rc = self.lib.orc_camera_rays(self.h, seed, C.byref(t), sample, _fp(o), _fp(d))
+        if rc != 0:
+            raise RuntimeError(f"orc_camera_rays failed: {rc}")
+        return o, d
 
     def render(self, rng=RNG_COUNTER, seed=1, threads=1, tiles=None, sample_begin=0, sample_end=0, slab_literal=0,
                rcp_approx=0, normals=False):

@@ -104,7 +104,7 @@ std::vector<phx_tile> make_tiles(uint32_t width, uint32_t height, uint32_t ts) {
   return out;
 }
 
-struct jitter_t { std::vector<V2> film; };
+struct jitter_t { std::vector<V2> film, lens; /* lens: RNG_SEQ only, [spp][1024] = pixel_samples[i].lens[j].{x,y}[k] at slot 8 j + k */ };
 
 // sampler_t::preprocess, sampling.cpp:89-143, in RNG_SEQ: consumes the stream exactly as the reference
 void sampler_preprocess_seq(seq_rng_t& rng, uint32_t spp, uint32_t nlights, jitter_t& J) {
@@ -120,7 +120,8 @@ void sampler_preprocess_seq(seq_rng_t& rng, uint32_t spp, uint32_t nlights, jitt
       if (j * spd + i < spp) J.film[j * spd + i] = V2(a, b);
     }
   }
-  for (uint32_t i = 0; i < spp; ++i) for (int k = 0; k < 128 * 8 * 2; ++k) rng.sample();  // lens table
+  J.lens.resize((size_t)spp * STREAM);  // lens table, sampling.cpp:108-109: x then y, slot by slot
+  for (uint32_t i = 0; i < spp; ++i) for (uint32_t k = 0; k < STREAM; ++k) { const float a = rng.sample(), b = rng.sample(); J.lens[(size_t)i * STREAM + k] = V2(a, b); }
   (void)nlights;
   for (int i = 0; i < 64 * 1024 * 3; ++i) rng.sample();  // 64 never-used light sample sets
 }
@@ -174,7 +175,23 @@ struct tile_renderer_t {
 
   float inv_len(float l2) const { return modes.rcp_approx ? rcp_approx(std::sqrt(l2)) : 1.0f / std::sqrt(l2); }
 
-  // camera::perspective_kernel_t::operator(), camera.hpp:80-159 (pinhole branch)
+  // camera::sample_aperture (camera.hpp:70-76) -> simd::concentric_sample_disc (math/simd/sampling.hpp:8-32) AS WRITTEN (A-21): `offset`
+  // (2 u - 1) is computed and never used, the raw samples in [0, 1) are; the constants named pi_o_2 / pi_o_4 hold 2 / pi and 4 / pi;
+  // select(m, l, r) returns r where m is set (float8.hpp:103-105), so the radius is the SMALLER-magnitude sample's partner and the angle the
+  // other branch's; sin / cos are libm's there, this build's binary64 kernels here (parity unpinned like every libm call of the path).
+  // A sample with a zero coordinate gives a non-finite angle and a NaN ray: it hits nothing, there and here.
+  static V2 lens_offset(const V2& u, float radius) {
+    const float c2 = (float)(2.0f / M_PI), c4 = (float)(4.0f / M_PI);
+    const bool x_gt_y = std::fabs(u.x) > std::fabs(u.y);
+    const float r = x_gt_y ? u.y : u.x;
+    const float theta1 = c4 * (u.y / u.x);
+    const float theta2 = c2 - c4 * (u.x / u.y);
+    const float theta = x_gt_y ? theta2 : theta1;
+    const float sn = m::sinf_(theta), cs = m::cosf_(theta);
+    return V2((r * cs) * radius, (r * sn) * radius);
+  }
+
+  // camera::perspective_kernel_t::operator(), camera.hpp:80-159
   void camera_rays(const phx_tile& tile, const V2& jit) {
     const phx_camera& cam = O.scene.camera;
     const float* M = cam.to_world;  // x[i][j] = M[4*i+j]
@@ -196,11 +213,21 @@ struct tile_renderer_t {
         d.y = (ndcy + d.y * stepy) * zoom;
         const float ool = inv_len(sv::dot(d, d));  // vector3_t::normalize, simd/vector.hpp:126-133
         d = V3(d.x * ool, d.y * ool, d.z * ool);
-        // transform_point(m, 0) and transform_vector(m, d), simd/matrix.hpp:58-104
+        V3 l(0.0f, 0.0f, 0.0f);
+        if (cam.aperture_radius != 0.0f) {  // camera.hpp:140-147: the lens samples advance with the slots, ++lens_sample per group of 8
+          const V2 u = (A.rng_mode == 0) ? J.lens[(size_t)cur_sample * STREAM + off] : V2(draw_f32(key_of_pixel(off), DIM_LENS_U), draw_f32(key_of_pixel(off), DIM_LENS_V));
+          const V2 lens = lens_offset(u, cam.aperture_radius);
+          const float ft = std::fabs(cam.focal_distance / d.z);
+          l = V3(lens.x, lens.y, 0.0f);
+          d = V3(d.x * ft - l.x, d.y * ft - l.y, d.z * ft - l.z);
+          const float ool2 = inv_len(sv::dot(d, d));
+          d = V3(d.x * ool2, d.y * ool2, d.z * ool2);
+        }
+        // transform_point(m, l) and transform_vector(m, d), simd/matrix.hpp:58-104
         V3 p;
-        { float t = 0.0f * M[0]; t = std::fmaf(0.0f, M[4], t); t = std::fmaf(0.0f, M[8], t); p.x = t + M[12]; }
-        { float t = 0.0f * M[1]; t = std::fmaf(0.0f, M[5], t); t = std::fmaf(0.0f, M[9], t); p.y = t + M[13]; }
-        { float t = 0.0f * M[2]; t = std::fmaf(0.0f, M[6], t); t = std::fmaf(0.0f, M[10], t); p.z = t + M[14]; }
+        { float t = l.x * M[0]; t = std::fmaf(l.y, M[4], t); t = std::fmaf(l.z, M[8], t); p.x = t + M[12]; }
+        { float t = l.x * M[1]; t = std::fmaf(l.y, M[5], t); t = std::fmaf(l.z, M[9], t); p.y = t + M[13]; }
+        { float t = l.x * M[2]; t = std::fmaf(l.y, M[6], t); t = std::fmaf(l.z, M[10], t); p.z = t + M[14]; }
         V3 w;
         { float t = d.x * M[0]; t = std::fmaf(d.y, M[4], t); w.x = std::fmaf(d.z, M[8], t); }
         { float t = d.x * M[1]; t = std::fmaf(d.y, M[5], t); w.y = std::fmaf(d.z, M[9], t); }
@@ -516,7 +543,6 @@ int orc_render(void* h, const render_args_t* args, float* film, float* normals, 
   oracle_t* o = (oracle_t*)h;
   if (!o || !args || !film) return 1;
   if (o->scene.lights.empty()) return 2;  // A-19: nlights-1 underflows
-  if (o->scene.camera.aperture_radius != 0.0f) return 3;
   const uint32_t W = o->scene.camera.film_width, H = o->scene.camera.film_height;
   std::vector<phx_tile> tiles = args->num_tiles ? std::vector<phx_tile>(args->tiles, args->tiles + args->num_tiles) : make_tiles(W, H, 32);
   for (auto& t : tiles) if (t.w * t.h > STREAM || t.w % 8 != 0) return 4;  // A-2
@@ -605,6 +631,24 @@ int orc_bench(void* h, const render_args_t* args, double min_seconds, float* fil
 int orc_jitter_table(uint64_t seed, uint32_t spp, float* out_xy) {
   jitter_t J; sampler_preprocess_counter(seed, spp, J);
   for (uint32_t i = 0; i < spp; ++i) { out_xy[2 * i] = J.film[i].x; out_xy[2 * i + 1] = J.film[i].y; }
+  return 0;
+}
+
+// the camera rays of one tile and one sample index (counter RNG): origins and directions of the tile's w x h slots, row-major
+int orc_camera_rays(void* h, uint64_t seed, const phx_tile* tile, uint32_t sample, float* o3, float* d3) {
+  oracle_t* o = (oracle_t*)h;
+  if (!o || !tile || !o3 || !d3) return 1;
+  if (tile->w * tile->h > STREAM || tile->w % 8 != 0 || sample >= o->opt.samples_per_pixel) return 4;
+  render_args_t a{}; a.rng_mode = 1; a.seed = seed; a.num_threads = 1;
+  jitter_t J; sampler_preprocess_counter(seed, o->opt.samples_per_pixel, J);
+  tile_renderer_t R(*o, a, nullptr, J);
+  R.cur_tile = *tile; R.cur_sample = sample;
+  R.rays = rays_t(); R.rays.resize(STREAM);
+  R.camera_rays(*tile, J.film[sample]);
+  for (uint32_t k = 0; k < tile->w * tile->h; ++k) {
+    o3[3 * k] = R.rays.px[k]; o3[3 * k + 1] = R.rays.py[k]; o3[3 * k + 2] = R.rays.pz[k];
+    d3[3 * k] = R.rays.wx[k]; d3[3 * k + 1] = R.rays.wy[k]; d3[3 * k + 2] = R.rays.wz[k];
+  }
   return 0;
 }
 

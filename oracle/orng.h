@@ -45,7 +45,8 @@ inline uint32_t draw_u32(uint32_t key, uint32_t dim) { return mix32(key + (dim +
 inline float draw_f32(uint32_t key, uint32_t dim) { return (float)(draw_u32(key, dim) >> 8) * (1.0f / 16777216.0f); }
 
 // dimensions of one path step (bounce b uses 8*b + DIM_*)
-enum { DIM_LIGHT_PICK = 0, DIM_LIGHT_U = 1, DIM_LIGHT_V = 2, DIM_RR = 3, DIM_BSDF_U = 4, DIM_BSDF_V = 5, DIMS_PER_STEP = 8 };
+enum { DIM_LIGHT_PICK = 0, DIM_LIGHT_U = 1, DIM_LIGHT_V = 2, DIM_RR = 3, DIM_BSDF_U = 4, DIM_BSDF_V = 5, DIMS_PER_STEP = 8,
+       DIM_LENS_U = 6, DIM_LENS_V = 7 /* the two spare dimensions of step 0: the thin lens */ };
 // pseudo pixel id used for the per-spp film jitter table
 static const uint32_t FILM_JITTER_STREAM = 0xffffffffu;
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cfloat>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -308,7 +309,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if (!d || !s) return fail(PHX_ERR_ARG, "preprocess: null argument");
   if (d->running) return fail(PHX_ERR_STATE, "preprocess while a frame is running");
   if (!s->meshes || !s->materials || s->num_materials == 0) return fail(PHX_ERR_ARG, "scene without meshes/materials");
-  if (s->camera.aperture_radius != 0.0f) return fail(PHX_ERR_ARG, "thin-lens cameras are not supported (reference path is broken, SURVEY A-21)");
+  if (!(std::fabs(s->camera.aperture_radius) <= FLT_MAX) || !(std::fabs(s->camera.focal_distance) <= FLT_MAX)) return fail(PHX_ERR_ARG, "camera: aperture radius / focal distance not finite");
   if (s->camera.film_width == 0 || s->camera.film_height == 0 || s->camera.film_width > 65535 || s->camera.film_height > 65535)
     return fail(PHX_ERR_ARG, "film size out of range");
   if (s->environment_material >= (int32_t)s->num_materials) return fail(PHX_ERR_ARG, "environment material out of range");
@@ -462,6 +463,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   sc.stepx = 1.0f / (float)s->camera.film_width; sc.stepy = 1.0f / (float)s->camera.film_height;
   sc.ratio = (float)s->camera.film_width / (float)s->camera.film_height;
   sc.width = s->camera.film_width; sc.height = s->camera.film_height;
+  sc.aperture_radius = s->camera.aperture_radius; sc.focal_distance = s->camera.focal_distance;  // thin lens iff aperture_radius != 0 (camera_t::is_pinhole)
   sc.max_depth = d->opt.path_depth;
   sc.stack_levels = bvh_depth;
   sc.num_elems = (uint32_t)bvh_elems;

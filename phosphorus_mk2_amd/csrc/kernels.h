@@ -50,6 +50,7 @@ struct DevScene {
   uint32_t any_per_hit;           // some material's closure weights depend on the hit (glass): k_shade<0>; none: k_shade<3>
   uint2* stack_spill;             // k_trace<., SPILL>: stack entries below the levels kept in LDS, [level - lds_levels][thread of the grid]
   uint32_t spill_stride;          // threads of the largest k_trace grid (0 = every level is in LDS)
+  float aperture_radius, focal_distance;  // camera_t (entities/camera.hpp:24-29): thin lens when aperture_radius != 0 (camera.hpp:140-147)
 };
 
 // counters (x CNT_STRIDE words): [0],[1] ray-queue lengths (ping-pong); [2],[3] shadow-queue lengths (by step parity); [4],[5] chunk cursors

@@ -84,9 +84,15 @@ __device__ __forceinline__ void block_append2(bool want_a, uint32_t* counter_a, 
 }
 
 // ---- camera rays ------------------------------------------------------------------------------------
-// camera::perspective_kernel_t (kernels/cpu/camera.hpp:80-159), pinhole.  Primary rays are never stored: the first
+// camera::perspective_kernel_t (kernels/cpu/camera.hpp:80-159).  Primary rays are never stored: the first
 // k_trace of a pass and the first k_shade both rebuild the ray of path `path` from the pixel table and the jitter table
 // (about 40 instructions) instead of writing and re-reading 32 B per path.
+// LENS (camera_t::aperture_radius != 0, set by the Blender importer when depth of field is on): camera.hpp:140-147 and
+// simd::concentric_sample_disc (math/simd/sampling.hpp:8-32) AS WRITTEN (SURVEY A-21): the raw samples in [0, 1) are mapped, not 2 u - 1;
+// the constants named pi_o_2 / pi_o_4 hold 2 / pi and 4 / pi; select(m, l, r) returns r where m is set (float8.hpp:103-105).  The two lens
+// samples are the spare dimensions 6 and 7 of the path's step 0 (the reference: a table of 1024 per sample index, sampling.cpp:108-109).
+// A sample with a zero coordinate gives a non-finite angle and a NaN ray, which hits nothing, there and here.
+template <bool LENS>
 __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers& pb, uint32_t path, uint32_t sample0, v3& p, v3& w) {
   const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;  // pixel-major: a wave = 64 samples of one pixel
   const uint32_t xy = pb.pix_xy[pix];
@@ -100,9 +106,27 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, const PassBuffers
   const float ool = 1.0f / sqrtf(sdot(d, d));
   d = v3(d.x * ool, d.y * ool, d.z * ool);
   const float* M = sc.cam_m;
+  if constexpr (LENS) {
+    const uint32_t key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+    const float ux = draw_f32(key, DIM_LENS_U), uy = draw_f32(key, DIM_LENS_V);
+    const float c2 = (float)(2.0f / M_PI), c4 = (float)(4.0f / M_PI);
+    const bool x_gt_y = fabsf(ux) > fabsf(uy);
+    const float r = x_gt_y ? uy : ux;
+    const float theta1 = c4 * (uy / ux), theta2 = c2 - c4 * (ux / uy);
+    const sincosf_t sc_t = sincosf_(x_gt_y ? theta2 : theta1);
+    const float lx = (r * sc_t.c) * sc.aperture_radius, ly = (r * sc_t.s) * sc.aperture_radius;
+    const float ft = fabsf(sc.focal_distance / d.z);
+    d = v3(d.x * ft - lx, d.y * ft - ly, d.z * ft - 0.0f);
+    const float ool2 = 1.0f / sqrtf(sdot(d, d));
+    d = v3(d.x * ool2, d.y * ool2, d.z * ool2);
+    { float t = lx * M[0]; t = fmaf(ly, M[4], t); t = fmaf(0.0f, M[8], t); p.x = t + M[12]; }
+    { float t = lx * M[1]; t = fmaf(ly, M[5], t); t = fmaf(0.0f, M[9], t); p.y = t + M[13]; }
+    { float t = lx * M[2]; t = fmaf(ly, M[6], t); t = fmaf(0.0f, M[10], t); p.z = t + M[14]; }
+  } else {
   { float t = 0.0f * M[0]; t = fmaf(0.0f, M[4], t); t = fmaf(0.0f, M[8], t); p.x = t + M[12]; }
   { float t = 0.0f * M[1]; t = fmaf(0.0f, M[5], t); t = fmaf(0.0f, M[9], t); p.y = t + M[13]; }
   { float t = 0.0f * M[2]; t = fmaf(0.0f, M[6], t); t = fmaf(0.0f, M[10], t); p.z = t + M[14]; }
+  }
   { float t = d.x * M[0]; t = fmaf(d.y, M[4], t); w.x = fmaf(d.z, M[8], t); }
   { float t = d.x * M[1]; t = fmaf(d.y, M[5], t); w.y = fmaf(d.z, M[9], t); }
   { float t = d.x * M[2]; t = fmaf(d.y, M[6], t); w.z = fmaf(d.z, M[10], t); }
@@ -643,7 +667,7 @@ __device__ __forceinline__ uint32_t packet_node_hit8(const uint32_t* w, const Sc
 #endif
 // RPL rays per lane: a packet is 64 x RPL consecutive paths (ray k of lane l is path base + 64 k + l).  The node tests are per packet,
 // so they are shared by more rays; the host picks RPL so that a packet stays inside one pixel's samples (launch_trace_primary).
-template <int RPL>
+template <int RPL, bool LENS = false /* thin-lens camera: camera_ray<true> */>
 __global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves_per_eu(PHX_PRIMARY_WAVES, 8))) k_trace_primary(DevScene sc, PassBuffers pb, uint32_t npaths, uint32_t sample0, int q, int sq) {
   extern __shared__ uint2 primary_lds[];  // [4 waves x PHX_MAX_BVH_DEPTH] one shared stack per wave, then [levels x 256] per-lane stacks of the fallback walk
   uint2* lane_stacks = primary_lds + (PHX_PRIMARY_BLOCK / 64) * PHX_MAX_BVH_DEPTH;
@@ -665,7 +689,7 @@ __global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves
   for (int k = 0; k < RPL; ++k) {
     idx[k] = base + 64u * k + lane;
     v3 co, cd;
-    camera_ray(sc, pb, min(idx[k], npaths - 1u), sample0, co, cd);  // rays past the end repeat the last one and write nothing
+    camera_ray<LENS>(sc, pb, min(idx[k], npaths - 1u), sample0, co, cd);  // rays past the end repeat the last one and write nothing
     r[k] = make_ray_ctx(co, cd);
     tbest[k] = FLT_MAX; hu[k] = 0.0f; hv[k] = 0.0f; htri[k] = 0xffffffffu; hprim[k] = 0;
   }
@@ -677,6 +701,8 @@ __global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves
     for (int k = 0; k < RPL; ++k) {
       LdsStack<0> st{lane_stacks + threadIdx.x, 0};
       Hit h;
+      // a NaN ray (LENS: a lens sample with a zero coordinate) hits nothing, but the conservative box test ignores NaNs: no walk of the whole tree
+      if constexpr (LENS) { const float chk = (r[k].o.x + r[k].o.y + r[k].o.z) + (r[k].d.x + r[k].d.y + r[k].d.z); if (!(fabsf(chk) <= FLT_MAX)) continue; }
       traverse8<false>(sc.pool, sc.grid, r[k].o, r[k].d, FLT_MAX, h, st);
       tbest[k] = h.t; hu[k] = h.u; hv[k] = h.v; htri[k] = h.tri;
     }
@@ -788,7 +814,7 @@ __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/util
 // The Lambert-only scenes (the soups, the Cornell box): shade + NEE + integrate of one path per thread in one go; HBM-stream bound.
 // Scenes with other closures go through k_shade_g below.
 template <int MATS /* 1 Lambert lobes only; 2 at most one Lambert lobe per material (DevScene::diffuse_only) */,
-          bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */>
+          bool FIRST /* queue q = the camera rays of this pass: nothing to read but the hit */, bool LENS = false /* FIRST: thin-lens camera */>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves_per_eu(4, 8))) k_shade(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   static_assert(MATS == 1 || MATS == 2, "general closures: k_shade_g");
   constexpr bool DIFFUSE_ONLY = true;
@@ -812,7 +838,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
     const float4 h = pb.hit[i];
     if (FIRST) {
       v3 co, cd;
-      camera_ray(sc, pb, i, sample0, co, cd);
+      camera_ray<LENS>(sc, pb, i, sample0, co, cd);
       a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
       bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
     } else {
@@ -1113,7 +1139,7 @@ __device__ __forceinline__ void ring_append(bool want, const float4& r0, const f
     }
   }
 }
-template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST>
+template <bool PERHIT /* some material's closure weights depend on the hit (glass) */, bool FIRST, bool LENS = false /* FIRST: thin-lens camera */>
 __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves_per_eu(PHX_SHADE_WAVES_G, 8))) k_shade_g(DevScene sc, PassBuffers pb, int q, int sq, uint32_t sample0) {
   constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
   static_assert(WINDOW <= 65536 && BLOCK >= NB + 2 && NB == 64, "perm holds 16-bit positions; one wave scans the NB material buckets");
@@ -1253,7 +1279,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         if constexpr (STAGE1) h = next_h; else h = pb.hit[i];
         if (FIRST) {
           v3 co, cd;
-          camera_ray(sc, pb, i, sample0, co, cd);
+          camera_ray<LENS>(sc, pb, i, sample0, co, cd);
           a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
           bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
         } else {
@@ -1572,6 +1598,7 @@ void for_each_trace_kernel(F&& f) {
 #endif
   f(reinterpret_cast<const void*>(&k_trace_rays<true>)); f(reinterpret_cast<const void*>(&k_trace_rays<false>));
   f(reinterpret_cast<const void*>(&k_trace_primary<1>)); f(reinterpret_cast<const void*>(&k_trace_primary<2>)); f(reinterpret_cast<const void*>(&k_trace_primary<4>));
+  f(reinterpret_cast<const void*>(&k_trace_primary<1, true>)); f(reinterpret_cast<const void*>(&k_trace_primary<2, true>)); f(reinterpret_cast<const void*>(&k_trace_primary<4, true>));
 }
 }  // namespace
 
@@ -1667,23 +1694,28 @@ static uint32_t shade_grid(const DevScene& sc, uint32_t capacity, uint32_t per_w
   return std::max(1u, std::min(need, resident * (uint32_t)mul));
 }
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays) {
+  const bool lens = camera_rays && sc.aperture_radius != 0.0f;  // camera_t::is_pinhole, entities/camera.hpp:37
   if (sc.diffuse_only) {
     const dim3 g((capacity + PHX_SHADE_BLOCK_D - 1) / PHX_SHADE_BLOCK_D), b(PHX_SHADE_BLOCK_D);
     if (sc.diffuse_only == 2) {
-      if (camera_rays) hipLaunchKernelGGL((k_shade<2, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+      if (lens) hipLaunchKernelGGL((k_shade<2, true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+      else if (camera_rays) hipLaunchKernelGGL((k_shade<2, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
       else hipLaunchKernelGGL((k_shade<2, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
     } else {
-      if (camera_rays) hipLaunchKernelGGL((k_shade<1, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+      if (lens) hipLaunchKernelGGL((k_shade<1, true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+      else if (camera_rays) hipLaunchKernelGGL((k_shade<1, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
       else hipLaunchKernelGGL((k_shade<1, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
     }
     return;
   }
   const dim3 g(shade_grid(sc, capacity, PHX_SHADE_BLOCK_G * PHX_SHADE_ITEMS_G, PHX_SHADE_BLOCK_G)), b(PHX_SHADE_BLOCK_G);
   if (sc.any_per_hit) {
-    if (camera_rays) hipLaunchKernelGGL((k_shade_g<true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    if (lens) hipLaunchKernelGGL((k_shade_g<true, true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else if (camera_rays) hipLaunchKernelGGL((k_shade_g<true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
     else hipLaunchKernelGGL((k_shade_g<true, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   } else {
-    if (camera_rays) hipLaunchKernelGGL((k_shade_g<false, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    if (lens) hipLaunchKernelGGL((k_shade_g<false, true, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
+    else if (camera_rays) hipLaunchKernelGGL((k_shade_g<false, true>), g, b, 0, stream, sc, pb, q, sq, sample0);
     else hipLaunchKernelGGL((k_shade_g<false, false>), g, b, 0, stream, sc, pb, q, sq, sample0);
   }
 }
@@ -1696,6 +1728,12 @@ void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuff
   uint32_t rpl = pb.num_samples % 256u == 0 ? 4u : pb.num_samples >= 16u ? 2u : 1u;
   if (rpl_env == 1 || rpl_env == 2 || rpl_env == 4) rpl = (uint32_t)rpl_env;
   const dim3 g((npaths + PHX_PRIMARY_BLOCK * rpl - 1) / (PHX_PRIMARY_BLOCK * rpl)), b(PHX_PRIMARY_BLOCK);
+  if (sc.aperture_radius != 0.0f) {  // thin lens: the rays of a packet leave from a disc, not a point (the packet's bounds know origins apart)
+    if (rpl == 4) hipLaunchKernelGGL((k_trace_primary<4, true>), g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
+    else if (rpl == 2) hipLaunchKernelGGL((k_trace_primary<2, true>), g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
+    else hipLaunchKernelGGL((k_trace_primary<1, true>), g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
+    return;
+  }
   if (rpl == 4) hipLaunchKernelGGL(k_trace_primary<4>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
   else if (rpl == 2) hipLaunchKernelGGL(k_trace_primary<2>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
   else hipLaunchKernelGGL(k_trace_primary<1>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);

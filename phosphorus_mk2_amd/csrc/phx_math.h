@@ -203,7 +203,8 @@ PHX_HD float draw_f32(uint32_t key, uint32_t dim) {
   uint32_t x = mix32(key + (dim + 1u) * 0x9e3779b9u);
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-enum { DIM_LIGHT_PICK = 0, DIM_LIGHT_U = 1, DIM_LIGHT_V = 2, DIM_RR = 3, DIM_BSDF_U = 4, DIM_BSDF_V = 5, DIMS_PER_STEP = 8 };
+enum { DIM_LIGHT_PICK = 0, DIM_LIGHT_U = 1, DIM_LIGHT_V = 2, DIM_RR = 3, DIM_BSDF_U = 4, DIM_BSDF_V = 5, DIMS_PER_STEP = 8,
+       DIM_LENS_U = 6, DIM_LENS_V = 7 /* the two spare dimensions of step 0: the thin lens (camera_ray<true>) */ };
 static const uint32_t FILM_JITTER_STREAM = 0xffffffffu;
 
 }  // namespace phx

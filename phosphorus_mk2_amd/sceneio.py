@@ -5,7 +5,8 @@ same top-level keys — `materials` (shader graphs, baked by closures.py), `data
 Differences, by necessity: geometry comes from Wavefront OBJ instead of Alembic (`.abc` needs the Alembic library,
 absent here); the camera block is completed into a look-at matrix (the reference's YAML camera decoder reads
 position/at/up and then drops them, src/codecs/scene/entities.hpp:18-33) with the Alembic importer's convention
-`fov = 2*atan2(sensor_width/2, focal_length)` (src/codecs/scene/alembic.hpp:69).
+`fov = 2*atan2(sensor_width/2, focal_length)` (src/codecs/scene/alembic.hpp:69); an optional `dof: {fstop, focus-distance}` block
+turns the thin lens on with the Blender importer's convention (plugins/blender/import.hpp:573-579).
 
 OBJ subset: v, vn, f (polygons are fan-triangulated; v//vn and v/vt/vn index forms), usemtl NAME (one face set per
 material, material ids = order of the YAML `materials` map, src/scene.cpp:84-90), `s off|0` / `s 1` (flat / smooth).
@@ -92,6 +93,11 @@ def load_scene(path, width=1280, height=720):
     to_world = look_at(cam.get("position", (0, 0, 0)), cam.get("at", (0, 0, -1)), cam.get("up", (0, 1, 0)))
     film = cam.get("film", {}) or {}
     camera = CameraDesc(int(film.get("width", width)), int(film.get("height", height)), fov, to_world)
+    dof = cam.get("dof") or {}
+    if dof:  # the Blender importer's depth of field (plugins/blender/import.hpp:573-579): focal length in mm, radius = lens / (2 f-stop) in m
+        fstop = max(float(dof.get("fstop", 2.8)), 1e-5)
+        camera.aperture_radius = (focal * 1e-3) / (2.0 * fstop)
+        camera.focal_distance = float(dof.get("focus-distance", 1.0))
     env = -1
     world = cfg.get("world") or {}
     if "environment" in world:

@@ -5,7 +5,7 @@ image gates additionally state the north-star tolerance (per-pixel L2 < 1e-4).""
 import numpy as np
 import pytest
 
-from conftest import bits_equal, max_pixel_l2, random_rays
+from conftest import aim_camera, bits_equal, max_pixel_l2, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -751,7 +751,7 @@ def test_error_behaviour(xpu):
     dark = scenes.cornell(32, 32); dark.meshes = dark.meshes[:5]  # no emissive face set (SURVEY A-19)
     with pytest.raises(xpu.DeviceError):
         dev.preprocess(dark)
-    lens = scenes.cornell(32, 32); lens.camera.aperture_radius = 0.1
+    lens = scenes.cornell(32, 32); lens.camera.aperture_radius = float("inf")  # a finite aperture is the thin lens (test_thin_lens_*)
     with pytest.raises(xpu.DeviceError):
         dev.preprocess(lens)
     assert xpu.HipDevice.discover(xpu.Options(host_only=True)) == []
@@ -1074,3 +1074,88 @@ def test_4k_film_in_several_batches(xpu, orc):
     for (x, y, w, h) in tiles:
         assert bits_equal(film[y:y + h, x:x + w, :3], img[y:y + h, x:x + w, :3])
         assert bits_equal(film[y:y + h, x:x + w, 4:7], nrm[y:y + h, x:x + w, :])
+
+
+def _with_lens(sc, aperture, focal, yaw=0.0, pitch=0.0):
+    if yaw or pitch:
+        aim_camera(sc, yaw, pitch)
+    sc.camera.aperture_radius, sc.camera.focal_distance = aperture, focal
+    return sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp,flight", [(3, 0), (16, 0), (256, 0), (40, 16)])
+def test_thin_lens_camera_matches_oracle(xpu, orc, spp, flight):
+    """camera_t::aperture_radius != 0 (the Blender importer sets it when depth of field is on): camera_ray<LENS> in k_trace_primary<RPL, true>
+    — 1, 2 and 4 rays per lane; a packet's rays leave from a disc, not a point — and in the first k_shade of a pass, against the oracle's
+    restatement of camera.hpp:140-147 (tests/test_thin_lens.py), bit for bit, on a ragged film with a turned camera"""
+    from phosphorus_mk2_amd import scenes
+    sc = _with_lens(scenes.soup(3000, width=72, height=40), 0.05, 2.5, 0.2, -0.1)
+    kw = {"samples_in_flight": flight} if flight else {}
+    film, st, (ref, ost) = _render_both(xpu, orc, sc, spp=spp, seed=11, **kw)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"]
+    assert bits_equal(film[..., :3], ref[..., :3]) and film[..., :3].max() > 0.05
+    pin, _ = xpu.render(_with_lens(scenes.soup(3000, width=72, height=40), 0.0, 2.5, 0.2, -0.1), spp=spp, seed=11, **kw)
+    assert not bits_equal(pin[..., :3], film[..., :3])  # the lens is really on
+
+
+@pytest.mark.gpu
+def test_thin_lens_camera_in_every_shade_kernel(xpu, orc):
+    """the first shade kernel of a pass rebuilds the camera ray: k_shade<1>, k_shade<2>, k_shade_g<false> and k_shade_g<true> each have a
+    thin-lens instantiation.  Cornell box (one Lambert lobe), several Lambert lobes, the 16 closure recipes, glass — with the normals
+    channel (the primary hit's shading normal) on the first"""
+    from phosphorus_mk2_amd import abi, scenes
+    D = abi.LOBE_DIFFUSE
+    mats = [scenes.MaterialDesc([scenes.LobeDesc(D, (0.4, 0.3, 0.2)), scenes.LobeDesc(D, (0.2, 0.3, 0.4))]), scenes.diffuse(0.73, 0.73, 0.73)]
+    cases = [("cornell", _with_lens(scenes.cornell(64, 48), 0.02, 1.5), 16),
+             ("lobes", _with_lens(scenes.soup(4000, width=96, height=64, materials=mats), 0.04, 2.2), 8),
+             ("zoo", _with_lens(scenes.multi_material_soup(4000, width=64, height=64), 0.04, 2.2, 0.1, 0.1), 16),
+             ("glass", _with_lens(scenes.glass_blobs(96, 64), 0.03, 2.0), 16)]
+    for name, sc, spp in cases:
+        normals = name == "cornell"
+        film, st, res = _render_both(xpu, orc, sc, spp=spp, seed=4, normals=normals)
+        ref, ost = res[0], res[1]
+        assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_masked"] == ost["rays_masked"], name
+        fin = np.isfinite(ref[..., :3]).all(axis=-1)
+        assert fin.mean() > 0.99 and np.array_equal(fin, np.isfinite(film[..., :3]).all(axis=-1)), name
+        assert bits_equal(film[..., :3][fin], ref[..., :3][fin]) and film[..., :3][fin].max() > 0.05, name
+        if normals:
+            assert bits_equal(film[..., 4:7], res[2]) and np.abs(res[2]).max() > 0.5, name
+
+
+@pytest.mark.gpu
+def test_thin_lens_zero_lens_sample_is_a_ray_that_hits_nothing(xpu, orc):
+    """a lens sample with a zero coordinate: non-finite angle, NaN ray (tests/test_thin_lens.py finds the pixels that own one by inverting
+    the counter RNG).  The device's conservative box test ignores NaNs, so the packet walk must not let such a ray in and the per-lane
+    walk must not start: the ray misses, the frame is finite and equal to the oracle's, in both walks (the tile on the film's axes has
+    packets of mixed octants)"""
+    from test_thin_lens import pixels_with_a_zero_lens_sample
+    from phosphorus_mk2_amd import scenes
+    W = H = 1024
+    found = pixels_with_a_zero_lens_sample(1, W, H, 64)
+    assert len(found) >= 2
+    tiles = sorted({(x // 32 * 32, y // 32 * 32, 32, 32) for x, y, _, _ in found[:4]})
+    sc = _with_lens(scenes.soup(20000, width=W, height=H), 0.05, 2.5)
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=64, paths_per_sample=1, path_depth=9))
+    dev.preprocess(sc)
+    film = xpu.Film(W, H, 4)
+    dev.start(sc, xpu.FrameState(1, xpu.CallbackTiles(tiles), film)); dev.join()
+    st = dev.stats(); dev.close()
+    ref, ost = orc.Oracle(sc, spp=64).render(rng=orc.RNG_COUNTER, seed=1, threads=8, tiles=tiles)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+    assert np.isfinite(film.data).all() and bits_equal(film.data[..., :3], ref[..., :3])
+    # the same pixels through the per-lane walk: aim the camera so that the film's axes (mixed direction octants) cross the first such tile
+    x, y, _, _ = found[0]
+    sc2 = _with_lens(scenes.soup(20000, width=W, height=H), 0.05, 2.5)
+    # pixel (x, y) looks along (fx, fy, -1) with the identity camera; turning the camera by the opposite angles puts the world's -z axis there
+    zoom = 1.12 * np.tan(1.9 / 2)
+    fx, fy = ((x + 0.5) / W - 0.5) * zoom, (0.5 - (y + 0.5) / H) * zoom
+    aim_camera(sc2, np.arctan(fx), -np.arctan(fy))
+    film2, st2 = xpu.Film(W, H, 4), None
+    dev = xpu.HipDevice.make(xpu.Options(samples_per_pixel=64, paths_per_sample=1, path_depth=9))
+    dev.preprocess(sc2)
+    dev.start(sc2, xpu.FrameState(1, xpu.CallbackTiles(tiles[:1]), film2)); dev.join()
+    st2 = dev.stats(); dev.close()
+    ref2, ost2 = orc.Oracle(sc2, spp=64).render(rng=orc.RNG_COUNTER, seed=1, threads=8, tiles=tiles[:1])
+    assert st2["rays_closest"] == ost2["rays_closest"] and st2["rays_shadow"] == ost2["rays_shadow"]
+    assert np.isfinite(film2.data).all() and bits_equal(film2.data[..., :3], ref2[..., :3])

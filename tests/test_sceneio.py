@@ -25,6 +25,24 @@ def test_yaml_obj_scene_loads_and_renders(tmp_path, orc):
     assert open(tmp_path / "out.pfm", "rb").read(16).startswith(b"PF\n64 48\n")
 
 
+def test_dof_block_turns_the_thin_lens_on_with_the_blender_convention(tmp_path, orc):
+    """plugins/blender/import.hpp:573-579: aperture_radius = lens[mm] * 1e-3 / (2 * max(fstop, 1e-5)), focal_distance = the focus distance"""
+    import shutil
+    import yaml
+    from phosphorus_mk2_amd import sceneio
+    shutil.copy(os.path.join(os.path.dirname(ROOM), "room.obj"), tmp_path / "room.obj")
+    cfg = yaml.safe_load(open(ROOM))
+    cfg["camera"]["dof"] = {"fstop": 1.4, "focus-distance": 3.0}
+    (tmp_path / "scene.yaml").write_text(yaml.safe_dump(cfg, sort_keys=False))
+    sc = sceneio.load_scene(str(tmp_path / "scene.yaml"))
+    focal = float(cfg["camera"].get("focal-length", 35.0))
+    assert abs(sc.camera.aperture_radius - focal * 1e-3 / 2.8) < 1e-9 and sc.camera.focal_distance == 3.0
+    assert sceneio.load_scene(ROOM).camera.aperture_radius == 0.0
+    a, _ = orc.Oracle(sc, spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=2)
+    b, _ = orc.Oracle(sceneio.load_scene(ROOM), spp=4).render(rng=orc.RNG_COUNTER, seed=1, threads=2)
+    assert np.isfinite(a).all() and (a != b).any() and abs(a[..., :3].mean() / b[..., :3].mean() - 1) < 0.1
+
+
 def test_bottom_up_film_sink_flips_tiles_like_the_blender_sink():
     """plugins/blender/sink.cpp:34-69: tile (x, y) lands at row height-h-y, rows reversed, primary alpha = 1"""
     import ctypes as C
