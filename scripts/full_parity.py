@@ -20,10 +20,12 @@ elif what.startswith("showroom:"):
     sc = scenes.showroom(int(what[9:]), width=1280, height=720, materials=[scenes.diffuse(0.6, 0.3, 0.2), scenes.glass(1.45), scenes.closure_zoo()[4]])
 else:
     sc = scenes.soup(int(what), seed=1234, width=1280, height=720)
+if os.environ.get("PHX_LENS"):  # "aperture_radius,focal_distance": the thin-lens camera on the same scene
+    sc.camera.aperture_radius, sc.camera.focal_distance = (float(v) for v in os.environ["PHX_LENS"].split(","))
 import bench
 threads = max(1, int(bench.host_cpus()[2]))  # the CPU share of this job: more oracle threads than that lose to context switches
 t0 = time.time(); film, st = xpu.render(sc, spp=spp, pps=1, depth=9, seed=1, native_sink=True, bvh_builder=builder); t_gpu = time.time() - t0
-out = {"scene": sc.name, "spp": spp, "builder": builder, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]], "oracle_threads": threads}
+out = {"scene": sc.name, "lens": [sc.camera.aperture_radius, sc.camera.focal_distance], "spp": spp, "builder": builder, "gpu_s": t_gpu, "gpu_rays": [st["rays_closest"], st["rays_shadow"], st["rays_masked"]], "oracle_threads": threads}
 for rule in (1, 0):
     orc.set_tie_rule(rule)
     t0 = time.time()
