@@ -29,6 +29,8 @@ for seed in range(first, first + n):
     kw = dict(bvh_builder=str(rng.choice(["host", "device", "auto"])), samples_in_flight=int(rng.choice([0, 1, 3])),
               tiles_per_batch=int(rng.choice([0, 1, 2, 5])), callback_tiles=bool(rng.random() < 0.3), native_sink=bool(rng.random() < 0.5))
     fseed = int(rng.integers(0, 1 << 30))
+    if seed % 4 == 3 and rng.random() < 0.35:  # a thin lens on a third of the deep-tree scenes too (_random_scene draws its own)
+        sc.camera.aperture_radius, sc.camera.focal_distance = float(rng.uniform(0.005, 0.08)), float(rng.uniform(1.5, 3.5))
     try:
         film, st = xpu.render(sc, spp=spp, pps=1, depth=depth, seed=fseed, normals=True, **kw)
         orc.set_tie_rule(1)

@@ -642,7 +642,8 @@ def test_two_devices_drain_one_tile_queue(xpu, orc):
 def _random_scene(seed):
     """a scene nobody designed: 2-4 meshes (indexed vertices shared between faces, smooth and flat faces mixed, per-vertex or
     per-corner normals), 3-6 materials drawn from the closure zoo and the glass node, 1-2 emissive face sets, an optional
-    environment, a camera that is not the identity, a film whose width and height are not multiples of the tile size"""
+    environment, a camera that is not the identity — on a third of the scenes with a thin lens —, a film whose width and height are not multiples of
+    the tile size"""
     from phosphorus_mk2_amd import abi, scenes
     rng = np.random.default_rng(seed)
     zoo = scenes.closure_zoo()
@@ -682,6 +683,8 @@ def _random_scene(seed):
     th = rng.uniform(-0.3, 0.3); M = np.eye(4, dtype=np.float32)
     M[0, 0] = np.cos(th); M[0, 2] = -np.sin(th); M[2, 0] = np.sin(th); M[2, 2] = np.cos(th); M[3, :3] = rng.uniform(-0.2, 0.2, 3)  # row-vector convention
     sc.camera.to_world = M
+    if rng.random() < 0.35:  # a thin lens on a third of the scenes (drawn last: the scenes of earlier rounds keep their geometry)
+        sc.camera.aperture_radius, sc.camera.focal_distance = float(rng.uniform(0.005, 0.08)), float(rng.uniform(1.5, 3.5))
     return sc
 
 
