@@ -174,7 +174,7 @@ double bvh8_sah_cost(const Bvh8& b, float c_node, float c_tri) {
 }
 
 void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, const uint32_t* prim_material) {
-  out.pool.clear(); out.depth = 1; out.num_nodes = 1; out.num_tris = 0;
+  out.pool.clear(); out.elem_of_prim.assign(n, 0xffffffffu); out.depth = 1; out.num_nodes = 1; out.num_tris = 0;
   auto empty_node = [](Node8& nd) {
     std::memset(&nd, 0, sizeof(nd));
     nd.ex = nd.ey = nd.ez = 127;
@@ -496,6 +496,7 @@ void build_bvh8(const float* tri_abc, uint32_t n, Bvh8& out, int num_threads, co
         T.prim = p;
         T.material = prim_material ? prim_material[p] : 0u;
         out.pool[ei].tri = T;
+        out.elem_of_prim[p] = ei;
         ++out.num_tris;
       } else {
         nd.imask |= (uint8_t)(1u << s);

@@ -15,6 +15,7 @@ struct Bvh8 {
   SceneGrid grid{};            // the grid the nodelets' origins are stored on
   uint32_t num_nodes = 0, num_tris = 0;
   uint32_t depth = 0;          // levels of nodelets (root = 1): bounds the traversal stack
+  std::vector<uint32_t> elem_of_prim;  // pool index of every primitive's triangle record
   float cost = 0.0f;           // modelled traversal cost of the collapse (sub(root) of the optimal-collapse programme; 0 if greedy)
 };
 

@@ -23,6 +23,7 @@ struct GpuBvh {
 // build can step around (the builder's scratch or pool did not fit the device's free memory; the tree is deeper than the traversal's
 // tables), 1 for everything else — a HIP error from a launch or a sync, or a builder that lost triangles: bugs, never to be hidden.
 enum { BVH_GPU_RECOVERABLE = 2 };
-int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen);
+// d_elem_of_prim (optional, n words of device memory): receives the pool index of every primitive's triangle record.
+int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen, uint32_t* d_elem_of_prim = nullptr);
 
 }  // namespace phx

@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(64 * DP_WAVES) k_collapse_dp(int n, const uint
 __global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const float* __restrict__ abc, const uint32_t* __restrict__ prim_material, const uint32_t* __restrict__ qa,
                                                  const uint32_t* __restrict__ qb, uint32_t count, uint32_t* __restrict__ qa_out, uint32_t* __restrict__ qb_out,
                                                  uint32_t* __restrict__ counters /* x BC_STRIDE words: [0] pool elements, [1] tris, [2] out queue, [3] nodes */, PoolElem* __restrict__ pool,
-                                                 const uint32_t* __restrict__ cut, const uint8_t* __restrict__ cut_count) {
+                                                 const uint32_t* __restrict__ cut, const uint8_t* __restrict__ cut_count, uint32_t* __restrict__ elem_of_prim /* or nullptr */) {
   const uint32_t e = blockIdx.x * 64 + threadIdx.x;
   if (e >= count) return;
   const uint32_t root2 = qa[e], n8 = qb[e];
@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const 
       R.e1x = t[6] - t[0]; R.e1y = t[7] - t[1]; R.e1z = t[8] - t[2];
       R.prim = p; R.material = prim_material[p]; R.pad1 = 0; R.pad2[0] = R.pad2[1] = R.pad2[2] = R.pad2[3] = 0;
       pool[ei].tri = R;
+      if (elem_of_prim) elem_of_prim[p] = ei;  // the shade kernels find a smooth face's vertex normals by the HIT's pool index (device.cpp: elem_normals)
     }
   }
   pool[n8].node = nd;
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(64) k_collapse(Tree2 T, SceneGrid grid, const 
 
 }  // namespace
 
-int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen) {
+int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_prim_material, uint32_t n, GpuBvh* out, char* err, size_t errlen, uint32_t* d_elem_of_prim) {
   std::memset(out, 0, sizeof(*out)); out->depth = 1;
   void* bufs[24]; int nb = 0;
   PoolElem* pool = nullptr;  // the output: freed by cleanup() unless the build succeeds
@@ -567,7 +568,7 @@ int build_bvh8_gpu(hipStream_t stream, const float* d_abc, const uint32_t* d_pri
   while (count > 0) {
     ++depth;
     hipLaunchKernelGGL(k_collapse, dim3((count + 63) / 64), dim3(64), 0, stream, T, grid, d_abc, d_prim_material, qa[cur], qb[cur], count, qa[cur ^ 1], qb[cur ^ 1],
-                       counters, pool, cut, cut_count);
+                       counters, pool, cut, cut_count, d_elem_of_prim);
     HCHK(hipMemcpyAsync(h_lines, counters, sizeof(h_lines), hipMemcpyDeviceToHost, stream));
     HCHK(hipStreamSynchronize(stream));
     for (int k = 0; k < 4; ++k) h_counters[k] = h_lines[k * BC_STRIDE];

@@ -92,7 +92,7 @@ struct phx_device {
   bool preprocessed = false;
 
   // scene
-  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_prim_normals; DevBuf<uint2> d_spill;
+  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_elem_normals; DevBuf<uint2> d_spill;
   DevBuf<DevMaterial> d_materials; DevBuf<DevMatLite> d_mat_lite; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
   DevScene scene{};
   uint32_t num_materials = 0;
@@ -100,7 +100,7 @@ struct phx_device {
   double preprocess_ms = 0, bvh_build_ms = 0;
 
   // pass buffers
-  DevBuf<float4> ro[2], rd[2], hit, so, sd, sc, pb, pr, pn;
+  DevBuf<float4> ro[2], rd[2], qs[2], hit, so, sd, sc, pr, pn;
   DevBuf<uint32_t> counters; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
   uint64_t jitter_seed = 0; uint32_t jitter_spp = 0;  // what the jitter table on the device was made for
   float* h_acc = nullptr; size_t h_acc_n = 0;  // pinned staging for add_tile
@@ -156,13 +156,13 @@ struct phx_device {
   }
   // HBM held by this device object (phx_stats::device_bytes)
   uint64_t device_bytes() const {
-    uint64_t b = d_pool.bytes() + d_prim_material.bytes() + d_prim_normals.bytes() + d_spill.bytes() + d_materials.bytes() + d_mat_lite.bytes() +
-                 d_lights.bytes() + d_light_tris.bytes() + hit.bytes() + so.bytes() + sd.bytes() + sc.bytes() + pb.bytes() + pr.bytes() + pn.bytes() +
+    uint64_t b = d_pool.bytes() + d_prim_material.bytes() + d_elem_normals.bytes() + d_spill.bytes() + d_materials.bytes() + d_mat_lite.bytes() +
+                 d_lights.bytes() + d_light_tris.bytes() + hit.bytes() + so.bytes() + sd.bytes() + sc.bytes() + pr.bytes() + pn.bytes() +
                  counters.bytes() + dstats.bytes() + pix_xy.bytes() + jitter.bytes() + acc.bytes();
-    for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes();
+    for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes() + qs[q].bytes();
     return b;
   }
-  // paths in flight this device may carry: up to 512 M (about 86 GB of queues + state: sized for 288 GB of HBM), but never more than 60 % of
+  // paths in flight this device may carry: up to 512 M (about 95 GB of queues + state: sized for 288 GB of HBM), but never more than 60 % of
   // what the device has free right now plus what this object already holds for queues (another device object, torch or RCCL may share the GPU)
   mutable uint64_t budget_bytes = 0;  // hipMemGetInfo costs ~0.1 ms a call: asked once per preprocess, not twice per frame
   uint64_t path_budget(size_t path_bytes) const {
@@ -172,8 +172,8 @@ struct phx_device {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         size_t held = 0;
-        for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n) * sizeof(float4);
-        held += (hit.n + so.n + sd.n + sc.n + pb.n + pr.n + pn.n) * sizeof(float4);
+        for (int q = 0; q < 2; ++q) held += (ro[q].n + rd[q].n + qs[q].n) * sizeof(float4);
+        held += (hit.n + so.n + sd.n + sc.n + pr.n + pn.n) * sizeof(float4);
         budget_bytes = (uint64_t)((double)(free_b + held) * 0.6);
       }
     }
@@ -397,6 +397,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if (builder > PHX_BVH_HOST_SAH) return fail(PHX_ERR_ARG, "unknown bvh_builder");
   bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri < 64u);
   GpuBvh g{};
+  DevBuf<uint32_t> d_elem_of_prim;  // any_smooth: pool index of every primitive's triangle record (the normals table is laid out by it)
   if (!want_host) {
     // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
     DevBuf<float> d_abc;
@@ -412,7 +413,8 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
       std::snprintf(msg, sizeof(msg), "forced %s failure (PHX_TEST_FAIL_DEVICE_BUILD)", brc == 1 ? "fatal" : "recoverable");
     }
 #endif
-    if (!brc) brc = build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg));
+    if (!brc && any_smooth && d_elem_of_prim.alloc(ntri)) brc = (int)BVH_GPU_RECOVERABLE, std::snprintf(msg, sizeof(msg), "%s", g_error.c_str());
+    if (!brc) brc = build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg), any_smooth ? d_elem_of_prim.p : nullptr);
     if (brc) {
       // An explicit DEVICE_LBVH request fails loudly, and so does AUTO when the device builder reports anything but a RECOVERABLE cause
       // (a HIP error from a launch or a sync, lost triangles: bugs that a silent 0.6-7 s host build would hide).  Under AUTO a device
@@ -433,6 +435,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
     build_bvh8(abc.data(), ntri, bvh, threads, prim_material.data());
     if ((rc = d->d_pool.upload(bvh.pool))) return rc;
+    if (any_smooth && (rc = d_elem_of_prim.upload(bvh.elem_of_prim))) return rc;
     bvh_depth = bvh.depth; bvh_node_count = bvh.num_nodes; bvh_elems = bvh.pool.size(); bvh_grid = bvh.grid;
     d->bvh_cost_model = bvh.cost; d->bvh_built_on_device = 0;
   } else {
@@ -444,17 +447,29 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   // k_trace / k_trace_rays keep one pending sibling group per level and lane in LDS (bvh8.h: PHX_MAX_BVH_DEPTH)
   if (bvh_depth > PHX_MAX_BVH_DEPTH)
     return fail(PHX_ERR_ARG, "tree too deep: " + std::to_string(bvh_depth) + " levels, the traversal stack in LDS holds " + std::to_string(PHX_MAX_BVH_DEPTH));
-  if ((rc = d->d_prim_normals.upload(prim_normals))) return rc;
   if ((rc = d->d_materials.upload(mats))) return rc;
   if ((rc = d->d_lights.upload(lights))) return rc;
   if ((rc = d->d_light_tris.upload(light_tris))) return rc;
+  if (any_smooth) {
+    // vertex normals by POOL ELEMENT (the index a hit record carries), so that the shade kernels request them with the triangle record and not
+    // after it; the smooth light triangles' `prim` becomes a pool index too (shading_normal on the light's face, spt.hpp:212-255)
+    DevBuf<float> d_prim_normals;
+    if ((rc = d_prim_normals.upload(prim_normals))) return rc;
+    if ((rc = d->d_elem_normals.alloc(9 * bvh_elems))) return rc;
+    launch_permute_normals(d->stream, d_prim_normals.p, d_elem_of_prim.p, d->d_elem_normals.p, ntri);
+    launch_remap_light_tris(d->stream, d->d_light_tris.p, (uint32_t)light_tris.size(), d_elem_of_prim.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(d->stream));
+  } else {
+    d->d_elem_normals.release();
+  }
 
   DevScene& sc = d->scene;
   sc.pool = reinterpret_cast<const uint32_t*>(d->d_pool.p);
   sc.tris = reinterpret_cast<const TriRec*>(d->d_pool.p);
   sc.grid = bvh_grid;
   sc.prim_material = d->d_prim_material.p;
-  sc.prim_normals = any_smooth ? d->d_prim_normals.p : nullptr;
+  sc.elem_normals = any_smooth ? d->d_elem_normals.p : nullptr;
   sc.materials = d->d_materials.p;
   sc.lights = d->d_lights.p; sc.light_tris = d->d_light_tris.p; sc.num_lights = (uint32_t)lights.size();
   sc.env_material = s->environment_material;
@@ -758,7 +773,7 @@ int phx_device::run_frame() {
   // pixel keeps the 64 lanes of a wave — and the 256 rays of a camera-ray packet — on ONE pixel.  (Round 3 took 8 M pixels whatever the spp:
   // the 3840x2160, 256-spp frame of BASELINE config 4 went through as 8 passes of 32 samples; as 8 batches of 256 samples it is 6.8 %
   // faster — camera rays 67.9 -> 36.0 ms, k_trace -4 %: profiles/r04_v_batch_probe.log.)
-  const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
+  const size_t path_bytes = 176u + (frame.normals_channel ? 16u : 0u);
   // (divided by the samples a pass will really carry: with an explicit samples_in_flight only P x S paths are ever in flight)
   const uint32_t pass_samples = std::max(1u, std::min(opt.samples_per_pixel, opt.samples_in_flight ? opt.samples_in_flight : opt.samples_per_pixel));
   const uint64_t pixel_cap = std::min<uint64_t>(8u << 20, std::max<uint64_t>(path_budget(path_bytes) / pass_samples, 64u << 10));
@@ -830,7 +845,7 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   const uint32_t spp = opt.samples_per_pixel;
   const uint32_t xs = frame.primary_components + (frame.normals_channel ? 3u : 0u);
   // bytes of queues + state per path in flight: ray queues 2 x 32, hit 16, shadow queue 48, path state 32 (+ 16 with normals)
-  const size_t path_bytes = 160u + (frame.normals_channel ? 16u : 0u);
+  const size_t path_bytes = 176u + (frame.normals_channel ? 16u : 0u);
   // paths in flight: the device's budget (path_budget: up to 512 M paths).  Deep bounces keep only a few percent of the paths alive, so
   // many paths per pass are what keeps late launches full; a batch that cannot carry all its samples at once splits the spp range
   // into equal passes.
@@ -867,14 +882,14 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   for (;;) {
     npaths = (size_t)P * S;
     rc = PHX_OK;
-    for (int q = 0; q < 2 && !rc; ++q) if ((rc = ro[q].alloc(npaths)) || (rc = rd[q].alloc(npaths))) break;
+    for (int q = 0; q < 2 && !rc; ++q) if ((rc = ro[q].alloc(npaths)) || (rc = rd[q].alloc(npaths)) || (rc = qs[q].alloc(npaths))) break;
     if (!rc) (void)((rc = hit.alloc(npaths)) || (rc = so.alloc(npaths)) || (rc = sd.alloc(npaths)) || (rc = sc.alloc(npaths)) ||
-                    (rc = pb.alloc(npaths)) || (rc = pr.alloc(npaths)) || (frame.normals_channel && (rc = pn.alloc(npaths))));
+                    (rc = pr.alloc(npaths)) || (frame.normals_channel && (rc = pn.alloc(npaths))));
     if (!rc) break;
     if (rc != PHX_ERR_OOM || S == 1) return rc;
     (void)hipGetLastError();
-    for (int q = 0; q < 2; ++q) { ro[q].release(); rd[q].release(); }
-    hit.release(); so.release(); sd.release(); sc.release(); pb.release(); pr.release(); pn.release();
+    for (int q = 0; q < 2; ++q) { ro[q].release(); rd[q].release(); qs[q].release(); }
+    hit.release(); so.release(); sd.release(); sc.release(); pr.release(); pn.release();
     budget_bytes = 0;  // the reading was stale: the next path_budget() — of this batch, of the next one, of the next frame — asks the device again
     S = std::min((S + 1) / 2, std::min(pick_samples(), spp));
   }
@@ -882,8 +897,8 @@ int phx_device::render_batch(const std::vector<phx_tile>& tiles, const std::vect
   tb_alloc = std::chrono::steady_clock::now();
 
   PassBuffers B{};
-  for (int q = 0; q < 2; ++q) { B.ro[q] = ro[q].p; B.rd[q] = rd[q].p; }
-  B.hit = hit.p; B.so = so.p; B.sd = sd.p; B.sc = sc.p; B.pb = pb.p; B.pr = pr.p;
+  for (int q = 0; q < 2; ++q) { B.ro[q] = ro[q].p; B.rd[q] = rd[q].p; B.qs[q] = qs[q].p; }
+  B.hit = hit.p; B.so = so.p; B.sd = sd.p; B.sc = sc.p; B.pr = pr.p;
   B.pn = frame.normals_channel ? pn.p : nullptr;
   B.counters = counters.p; B.stats = dstats.p; B.pix_xy = pix_xy.p; B.jitter = jitter.p; B.acc = acc.p;
   B.num_pixels = P; B.xstride = xs; B.normals_offset = frame.normals_channel ? frame.primary_components : 0;

@@ -32,7 +32,8 @@ struct DevScene {
   const TriRec* tris;             // the same pool seen as triangle records (hit records carry pool indices)
   SceneGrid grid;                 // grid of the nodelets' origins
   const uint32_t* prim_material;  // per primitive (scene_t::triangles() order): material | smooth << 31
-  const float* prim_normals;      // 9 floats per primitive (n0,n1,n2) or nullptr when no face is smooth
+  const float* elem_normals;      // 9 floats (n0,n1,n2) per POOL ELEMENT — indexed like `tris`, by the hit's pool index, so that the normals are requested
+                                  // WITH the triangle record, not after it (round 6; entries of nodelets are never read) — or nullptr when no face is smooth
   const DevMaterial* materials;
   const DevMatLite* mat_lite;     // diffuse_only == 2: the same table, 32 B per material
   const DevLight* lights;
@@ -81,7 +82,8 @@ struct PassBuffers {
   float4* ro[2]; float4* rd[2];
   float4* hit;
   float4* so; float4* sd; float4* sc;
-  float4* pb; float4* pr;
+  float4* qs[2];              // path state (beta, depth) of the queue entry: it travels WITH the ray (round 6; before: an array by path id, a dependent gather)
+  float4* pr;
   float4* pn;                 // primary normal + hit flag per path (only when the normals channel is on)
   uint32_t* counters;         // CNT_WORDS
   DevStats* stats;
@@ -114,6 +116,10 @@ void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuff
 // shades queue q, appends survivors to queue q^1 and NEE rays to shadow queue sq
 void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb, int q, int sq, uint32_t capacity, uint32_t sample0, int camera_rays);
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);
+// preprocess: vertex normals from scene_t::triangles() order to pool-element order (elem_of_prim: the builders' map), and the smooth light
+// triangles' `prim` from primitive to pool element (they look their normals up in the same table)
+void launch_permute_normals(hipStream_t stream, const float* prim_normals, const uint32_t* elem_of_prim, float* elem_normals, uint32_t num_prims);
+void launch_remap_light_tris(hipStream_t stream, DevLightTri* light_tris, uint32_t num_light_tris, const uint32_t* elem_of_prim);
 void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width);
 
 // stage-level entry points (synchronous helpers for the parity tests)

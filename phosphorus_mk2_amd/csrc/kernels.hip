@@ -797,14 +797,30 @@ __global__ void __launch_bounds__(PHX_PRIMARY_BLOCK) __attribute__((amdgpu_waves
 }
 
 // ---- shade + next-event estimation + integrate ------------------------------------------------------
-__device__ __forceinline__ v3 shading_normal(const DevScene& sc, uint32_t prim, bool smooth, const v3& e0, const v3& e1, float u, float v) {
+__device__ __forceinline__ v3 shading_normal(const DevScene& sc, uint32_t elem /* pool index of the triangle record */, bool smooth, const v3& e0, const v3& e1, float u, float v) {
   if (smooth) {  // mesh_t::shading_parameters, src/mesh.cpp:187-199
     const float w = 1 - u - v;
-    const float* pn = sc.prim_normals + 9 * (size_t)prim;
+    const float* pn = sc.elem_normals + 9 * (size_t)elem;
     const v3 n0(pn[0], pn[1], pn[2]), n1(pn[3], pn[4], pn[5]), n2(pn[6], pn[7], pn[8]);
     return normalize_inplace(w * n0 + u * n1 + v * n2);
   }
   return normalize_inplace(cross(e0, e1));  // (v1-v0) x (v2-v0), never flipped (mesh.cpp:201-215)
+}
+// k_shade_g: the three vertex normals of the hit's pool element are requested TOGETHER WITH its triangle record — whether the face is smooth
+// is a bit of that record — and used or dropped when it has landed (flat faces of a scene with smooth ones pay a 36-byte gather for nothing;
+// scenes without smooth faces have no table and no request)
+struct VertexNormals { v3 n0, n1, n2; };
+__device__ __forceinline__ VertexNormals request_vertex_normals(const DevScene& sc, uint32_t elem) {
+  VertexNormals N{v3(0.0f), v3(0.0f), v3(0.0f)};
+  if (sc.elem_normals) {
+    const float* pn = sc.elem_normals + 9 * (size_t)elem;
+    N.n0 = v3(pn[0], pn[1], pn[2]); N.n1 = v3(pn[3], pn[4], pn[5]); N.n2 = v3(pn[6], pn[7], pn[8]);
+  }
+  return N;
+}
+__device__ __forceinline__ v3 shading_normal(const VertexNormals& N, bool smooth, const v3& e0, const v3& e1, float u, float v) {
+  if (smooth) { const float w = 1 - u - v; return normalize_inplace(w * N.n0 + u * N.n1 + v * N.n2); }  // the same expression as above
+  return normalize_inplace(cross(e0, e1));
 }
 
 __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/utils/color.hpp:13-16
@@ -831,7 +847,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   const bool live = i < count;
   bool alive = false, want_shadow = false, masked = false;
   uint32_t path = 0, next_specular = 0;
-  v3 nxt_o, nxt_d, sh_o, sh_d, contrib;
+  v3 nxt_o, nxt_d, sh_o, sh_d, contrib, nxt_beta;
+  uint32_t nxt_depth = 0;
   float sh_t = 0.0f;
   if (live) {
     float4 a, b, bd;
@@ -842,12 +859,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
       a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
       bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
     } else {
-      a = pb.ro[q][i]; b = pb.rd[q][i];
+      a = pb.ro[q][i]; b = pb.rd[q][i]; bd = pb.qs[q][i];
     }
     const uint32_t pbits = f2u(a.w);
     path = pbits & 0x7fffffffu;
     const bool specular = (pbits >> 31) != 0;
-    if (!FIRST) bd = pb.pb[path];
     v3 beta(bd.x, bd.y, bd.z);
     // radiance is only read-modified-written when this step adds something: out += beta * e with e == 0 and a
     // finite beta leaves `out` unchanged bit for bit (out is never -0), so the 32 B of traffic are skipped
@@ -864,7 +880,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
       const uint32_t pm = T.material;
       const v3 p = o + d * h.x;            // hits.p = p + wi*d
       const v3 wo = -d;                    // hits.wi = -wi
-      const v3 n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+      const v3 n = shading_normal(sc, tri, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
       // material_t::evaluate (material.cpp:419-458): the closure list at this hit.  A constant recipe is read from the table; a
       // material with a hit-dependent weight (glass: Fresnel-driven mix) gets its weights resolved for (n, hits.wi) first.
       const DevMaterial* mp = &sc.materials[pm & 0x7fffffffu];
@@ -953,7 +969,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
       if (FIRST && pb.pn) pb.pn[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       masked = true;  // a miss still occupies a (MASKED|SHADOW) slot in the reference's shadow stream (spt.hpp:138-141)
     }
-    if (alive) pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));  // only the next k_shade of a surviving path reads it
+    nxt_beta = beta; nxt_depth = depth;  // only the next k_shade of a surviving path reads them: they leave with the ray below
     if (FIRST) {  // r = 0 + beta * e: every path's radiance is written here, nothing is read
       const v3 rad = v3(0.0f) + v3(bd.x, bd.y, bd.z) * add_e;
       pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
@@ -972,6 +988,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   if (alive) {
     pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
     pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
+    pb.qs[q ^ 1][no] = make_float4(nxt_beta.x, nxt_beta.y, nxt_beta.z, u2f(nxt_depth));  // the path's state travels with its ray
   }
   if (want_shadow) {
     pb.so[ns] = make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path));
@@ -1012,6 +1029,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #endif
 #ifndef PHX_SHADE_PREFETCH_PERHIT
 #define PHX_SHADE_PREFETCH_PERHIT 0  /* the same two stages in the per-hit (glass) instantiations: measured worthless in round 5 (profiles/r05_c_shade_prefetch_glass_ab.log) */
+#endif
+#ifndef PHX_SHADE_TRI_LDS
+#define PHX_SHADE_TRI_LDS 1  /* instantiations without prefetch stages (per-hit closures): the sort phase keeps each hit's pool index beside the permutation (16 KB of LDS), so that a round requests the triangle record and the vertex normals WITH the hit record and the ray instead of after the hit record has landed */
 #endif
 #ifndef PHX_SCALAR_F_PERHIT
 #define PHX_SCALAR_F_PERHIT 1  /* the per-hit (glass) instantiations read the recipe through the scalar cache too: with the ring append the kernel has the registers (127 / 123 VGPRs, no scratch; round 5: 16 B of scratch): closed showroom -4.4 %, glass showroom -2.9 % shade time (profiles/r06_i_perhit_knobs_ab.log) */
@@ -1144,7 +1164,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
   static_assert(WINDOW <= 65536 && BLOCK >= NB + 2 && NB == 64, "perm holds 16-bit positions; one wave scans the NB material buckets");
 #if PHX_SHADE_RING
-  __shared__ float4 ring_a[2 * 2 * PHX_RING_BLK];  // survivors: (o, path | SPECULAR << 31), (d, tmax)
+  __shared__ float4 ring_a[3 * 2 * PHX_RING_BLK];  // survivors: (o, path | SPECULAR << 31), (d, tmax), (beta, depth)
   __shared__ float4 ring_b[3 * 2 * PHX_RING_BLK];  // NEE rays: (o, path), (d, tmax), (beta * Li)
   __shared__ RingCtl ring_ctl[2];
   __shared__ uint32_t slice_next;  // PHX_SHADE_DYN_SLICES: the window's next 64-slot slice
@@ -1154,6 +1174,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #endif
   __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
   __shared__ uint16_t perm[WINDOW];
+  constexpr bool TRI_LDS = PHX_SHADE_TRI_LDS && !(PHX_SHADE_PREFETCH >= 1 && (!PERHIT || PHX_SHADE_PREFETCH_PERHIT >= 1));  // = !STAGE1 below
+  __shared__ uint32_t tri_sorted[TRI_LDS ? WINDOW : 1];  // the hit's pool index (0xffffffff = miss) at its sorted position
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   if (blockIdx.x == 0 && threadIdx.x == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
   PHX_PHASE_DECL
@@ -1188,8 +1210,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     if (threadIdx.x == 0) slice_next = 0u;
 #endif
     __syncthreads();
-    uint32_t keys[ITEMS];
-    { uint32_t tri_[ITEMS]; request_tris(base, tri_); request_keys(tri_, keys); }
+    uint32_t keys[ITEMS], tri_[ITEMS];
+    request_tris(base, tri_); request_keys(tri_, keys);
     uint32_t ranks[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) ranks[k] = atomicAdd(&bucket[keys[k]], 1u);
@@ -1204,7 +1226,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) perm[bucket[keys[k]] + ranks[k]] = (uint16_t)(k * BLOCK + threadIdx.x);
+    for (int k = 0; k < ITEMS; ++k) {
+      const uint32_t at = bucket[keys[k]] + ranks[k];
+      perm[at] = (uint16_t)(k * BLOCK + threadIdx.x);
+      if constexpr (TRI_LDS) tri_sorted[at] = tri_[k];
+    }
     __syncthreads();
     PHX_PHASE(0)  // the window's sort by material
 #if PHX_SHADE_TIMING
@@ -1242,13 +1268,14 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         }
       }
     };
-    // second stage (PHX_SHADE_PREFETCH 2): what depends on those records — the path state and the triangle record — is requested right
-    // after the append, when the first stage has landed, and travels while this round's queue entries are stored
+    // second stage (PHX_SHADE_PREFETCH 2): the triangle record, which depends on the hit record, is requested right after the append, when
+    // the first stage has landed, and travels while this round's queue entries are stored; the path state — since round 6 a queue record like
+    // the ray, no longer a gather by path id — goes with it (four registers that need not live across the append)
     float4 next_bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // FIRST: state_t::reset: beta = 1, depth = 0
     TriRec next_T{};
     auto request_round_dependents = [&]() {
       if (next_live) {
-        if (!FIRST) next_bd = pb.pb[f2u(next_a.w) & 0x7fffffffu];
+        if (!FIRST) next_bd = pb.qs[q][next_i];
         const uint32_t tri = f2u(next_h.w);
         if (tri != 0xffffffffu) next_T = sc.tris[tri];
       }
@@ -1277,34 +1304,42 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         float4 a, b, bd;
         float4 h;
         if constexpr (STAGE1) h = next_h; else h = pb.hit[i];
+        // TRI_LDS: the hit's pool index comes from the sort phase (LDS), so its triangle record and vertex normals are requested HERE, beside the
+        // hit record and the ray, not after the hit record has landed (one memory round trip less on the critical path of a round)
+        uint32_t tri_early = 0xffffffffu; TriRec T_early{}; VertexNormals VN_early{v3(0.0f), v3(0.0f), v3(0.0f)};
+        if constexpr (TRI_LDS) {
+          tri_early = tri_sorted[sorted_slot(k)];
+          if (tri_early != 0xffffffffu) { T_early = sc.tris[tri_early]; VN_early = request_vertex_normals(sc, tri_early); }
+        }
         if (FIRST) {
           v3 co, cd;
           camera_ray<LENS>(sc, pb, i, sample0, co, cd);
           a = make_float4(co.x, co.y, co.z, u2f(i)); b = make_float4(cd.x, cd.y, cd.z, FLT_MAX);
           bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // state_t::reset: beta = 1, depth = 0
         } else {
-          if constexpr (STAGE1) { a = next_a; b = next_b; } else { a = pb.ro[q][i]; b = pb.rd[q][i]; }
+          if constexpr (STAGE1) { a = next_a; b = next_b; bd = next_bd; } else { a = pb.ro[q][i]; b = pb.rd[q][i]; bd = pb.qs[q][i]; }
         }
         const uint32_t pbits = f2u(a.w);
         path = pbits & 0x7fffffffu;
         const bool specular = (pbits >> 31) != 0;
-        if constexpr (!FIRST) { if constexpr (STAGE1) bd = next_bd; else bd = pb.pb[path]; }
         beta = v3(bd.x, bd.y, bd.z);
         depth = f2u(bd.w);
         const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
         const uint32_t xy = pb.pix_xy[pix];
         key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
-        const uint32_t tri = f2u(h.w);
+        const uint32_t tri = TRI_LDS ? tri_early : f2u(h.w);
         const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
         v3 add_e(0.0f); bool add_rad = false;
         if (tri != 0xffffffffu) {
           hit_surface = true;
+          VertexNormals VN;
           TriRec T;
-          if constexpr (STAGE1) T = next_T; else T = sc.tris[tri];
+          if constexpr (TRI_LDS) { VN = VN_early; T = T_early; }
+          else { VN = request_vertex_normals(sc, tri); if constexpr (STAGE1) T = next_T; else T = sc.tris[tri]; }
           const uint32_t pm = T.material;
           p = o + d * h.x;            // hits.p = p + wi*d
           wo = -d;                    // hits.wi = -wi
-          n = shading_normal(sc, T.prim, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+          n = shading_normal(VN, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
           mat = pm & 0x7fffffffu;  // material_t::evaluate (material.cpp:419-458): the closure recipe at this hit
           if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
           if (depth == 0 || specular) { const DevMaterial& m = sc.materials[mat]; add_e = v3(m.ex, m.ey, m.ez); add_rad = true; }  // spt.hpp:177-179
@@ -1414,7 +1449,6 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
             }
           }
         }
-        if (alive) pb.pb[path] = make_float4(beta.x, beta.y, beta.z, u2f(depth));  // only the next shade of a surviving path reads it
         // both queues in one go: two barriers and two concurrent atomics per round (appending the NEE ray before roulette and sampling
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
@@ -1426,8 +1460,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           const v3 nxt_o = p + n * off;
           ring_append<3>(want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
                          &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->ring_watchdog);
-          ring_append<2>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
-                         &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr, &pb.stats->ring_watchdog);
+          ring_append<3>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX),
+                         make_float4(beta.x, beta.y, beta.z, u2f(depth)),  // the path's state travels with its ray: only the next shade of a surviving path reads it
+                         &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], pb.qs[q ^ 1], &pb.stats->ring_watchdog);
         }
         PHX_PHASE(4)  // the append: slot reservation, records to LDS, commit; for one wave in BLK / 64 rounds the flush of a block
         if constexpr (STAGE2) request_round_dependents();
@@ -1449,6 +1484,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           const v3 nxt_o = p + n * off;
           pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
           pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
+          pb.qs[q ^ 1][no] = make_float4(beta.x, beta.y, beta.z, u2f(depth));
         }
 #endif
         PHX_PHASE(5)  // the stores of the two queue entries (waited for: the probe charges them here, the product build does not wait)
@@ -1470,7 +1506,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     // blocks ago, or nothing at all — must not reach a queue, where a path id is an index.  The frame is reported as failed anyway.  The
     // ring-watchdog twin library faulted the GPU on exactly this until the guard was added: tests/test_gpu_parity.py::test_append_ring_timeout_…)
     if (left && !ring_ctl[w].dead) {
-      if (w == 0u) ring_flush<2>(ring_a, first, left, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], nullptr);
+      if (w == 0u) ring_flush<3>(ring_a, first, left, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], pb.qs[q ^ 1]);
       else ring_flush<3>(ring_b, first, left, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc);
     }
   }
@@ -1737,6 +1773,26 @@ void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuff
   if (rpl == 4) hipLaunchKernelGGL(k_trace_primary<4>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
   else if (rpl == 2) hipLaunchKernelGGL(k_trace_primary<2>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
   else hipLaunchKernelGGL(k_trace_primary<1>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
+}
+namespace {
+__global__ void k_permute_normals(const float* __restrict__ prim_normals, const uint32_t* __restrict__ elem_of_prim, float* __restrict__ elem_normals, uint32_t n) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t e = elem_of_prim[p];
+  if (e == 0xffffffffu) return;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) elem_normals[9 * (size_t)e + k] = prim_normals[9 * (size_t)p + k];
+}
+__global__ void k_remap_light_tris(DevLightTri* __restrict__ lt, uint32_t n, const uint32_t* __restrict__ elem_of_prim) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && lt[i].smooth) lt[i].prim = elem_of_prim[lt[i].prim];
+}
+}  // namespace
+void launch_permute_normals(hipStream_t stream, const float* prim_normals, const uint32_t* elem_of_prim, float* elem_normals, uint32_t num_prims) {
+  if (num_prims) hipLaunchKernelGGL(k_permute_normals, dim3((num_prims + 255) / 256), dim3(256), 0, stream, prim_normals, elem_of_prim, elem_normals, num_prims);
+}
+void launch_remap_light_tris(hipStream_t stream, DevLightTri* light_tris, uint32_t num_light_tris, const uint32_t* elem_of_prim) {
+  if (num_light_tris) hipLaunchKernelGGL(k_remap_light_tris, dim3((num_light_tris + 255) / 256), dim3(256), 0, stream, light_tris, num_light_tris, elem_of_prim);
 }
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv) {
   hipLaunchKernelGGL(k_film, dim3((pb.num_pixels + PHX_FILM_PIX - 1) / PHX_FILM_PIX), dim3(256), 0, stream, pb, num_samples, inv);
