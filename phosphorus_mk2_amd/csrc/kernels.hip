@@ -325,7 +325,7 @@ __device__ __forceinline__ void trace_stream(const DevScene& sc, const PassBuffe
             float4 a, b;
             if (phase == 0u) { a = pb.so[my]; b = pb.sd[my]; } else { a = ro[my]; b = rd[my]; }
             r = make_ray_ctx(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
-            tbest = b.w; path = f2u(a.w);
+            tbest = phase == 0u ? b.w : FLT_MAX; path = f2u(a.w);  // a closest-hit ray always starts at FLT_MAX (spt.hpp:301-305): the queue's fourth word carries the path's RNG key instead
           }
           hu = 0.f; hv = 0.f; htri = 0xffffffffu; hprim = 0; idx = my;
           ng_base = 0; ng_hits = 0x80000000u; tg = 0; tq = 0; sp = 0;  // the root as a one-child group (bvh8.h: traverse8)
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   bool alive = false, want_shadow = false, masked = false;
   uint32_t path = 0, next_specular = 0;
   v3 nxt_o, nxt_d, sh_o, sh_d, contrib, nxt_beta;
-  uint32_t nxt_depth = 0;
+  uint32_t nxt_depth = 0, key = 0;
   float sh_t = 0.0f;
   if (live) {
     float4 a, b, bd;
@@ -870,9 +870,15 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
     v3 add_e(0.0f); bool add_rad = false;
     const bool beta_finite = isfinite(bd.x) && isfinite(bd.y) && isfinite(bd.z);
     uint32_t depth = f2u(bd.w);
-    const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
-    const uint32_t xy = pb.pix_xy[pix];
-    const uint32_t key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+    // the path's RNG key: computed once, by the first shade of the pass, then carried in the ray record's fourth word (a closest-hit ray's
+    // tmax is always FLT_MAX) — a dependent gather (pixel table), an integer division and four hash rounds less per later step
+    if (FIRST) {
+      const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
+      const uint32_t xy = pb.pix_xy[pix];
+      key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+    } else {
+      key = f2u(b.w);
+    }
     const uint32_t tri = f2u(h.w);
     const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
     if (tri != 0xffffffffu) {
@@ -987,7 +993,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   block_append2<PHX_SHADE_BLOCK>(alive, &pb.counters[(q ^ 1) * CNT_STRIDE], want_shadow, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], lds_cnt, no, ns);
   if (alive) {
     pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
-    pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
+    pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, u2f(key));  // (d, the path's RNG key)
     pb.qs[q ^ 1][no] = make_float4(nxt_beta.x, nxt_beta.y, nxt_beta.z, u2f(nxt_depth));  // the path's state travels with its ray
   }
   if (want_shadow) {
@@ -1164,7 +1170,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
   constexpr int BLOCK = PHX_SHADE_BLOCK_G, ITEMS = PHX_SHADE_ITEMS_G, WINDOW = BLOCK * ITEMS, NB = PHX_SHADE_BUCKETS;
   static_assert(WINDOW <= 65536 && BLOCK >= NB + 2 && NB == 64, "perm holds 16-bit positions; one wave scans the NB material buckets");
 #if PHX_SHADE_RING
-  __shared__ float4 ring_a[3 * 2 * PHX_RING_BLK];  // survivors: (o, path | SPECULAR << 31), (d, tmax), (beta, depth)
+  __shared__ float4 ring_a[3 * 2 * PHX_RING_BLK];  // survivors: (o, path | SPECULAR << 31), (d, RNG key), (beta, depth)
   __shared__ float4 ring_b[3 * 2 * PHX_RING_BLK];  // NEE rays: (o, path), (d, tmax), (beta * Li)
   __shared__ RingCtl ring_ctl[2];
   __shared__ uint32_t slice_next;  // PHX_SHADE_DYN_SLICES: the window's next 64-slot slice
@@ -1324,9 +1330,13 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         const bool specular = (pbits >> 31) != 0;
         beta = v3(bd.x, bd.y, bd.z);
         depth = f2u(bd.w);
-        const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
-        const uint32_t xy = pb.pix_xy[pix];
-        key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+        if (FIRST) {  // the path's RNG key: computed here once, then carried in the ray record's fourth word (k_shade above)
+          const uint32_t pix = path / pb.num_samples, s = path - pix * pb.num_samples;
+          const uint32_t xy = pb.pix_xy[pix];
+          key = path_key(pb.seed, (xy >> 16) * sc.width + (xy & 0xffffu), sample0 + s);
+        } else {
+          key = f2u(b.w);
+        }
         const uint32_t tri = TRI_LDS ? tri_early : f2u(h.w);
         const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
         v3 add_e(0.0f); bool add_rad = false;
@@ -1460,7 +1470,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           const v3 nxt_o = p + n * off;
           ring_append<3>(want_shadow, make_float4(sh_o.x, sh_o.y, sh_o.z, u2f(path)), make_float4(sh_d.x, sh_d.y, sh_d.z, sh_t), make_float4(contrib.x, contrib.y, contrib.z, 0.0f),
                          &ring_ctl[1], ring_b, &pb.counters[CNT_SHADOW + sq * CNT_STRIDE], pb.so, pb.sd, pb.sc, &pb.stats->ring_watchdog);
-          ring_append<3>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX),
+          ring_append<3>(alive, make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31))), make_float4(nxt_d.x, nxt_d.y, nxt_d.z, u2f(key)),
                          make_float4(beta.x, beta.y, beta.z, u2f(depth)),  // the path's state travels with its ray: only the next shade of a surviving path reads it
                          &ring_ctl[0], ring_a, &pb.counters[(q ^ 1) * CNT_STRIDE], pb.ro[q ^ 1], pb.rd[q ^ 1], pb.qs[q ^ 1], &pb.stats->ring_watchdog);
         }
@@ -1483,7 +1493,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         if (alive) {
           const v3 nxt_o = p + n * off;
           pb.ro[q ^ 1][no] = make_float4(nxt_o.x, nxt_o.y, nxt_o.z, u2f(path | (next_specular << 31)));
-          pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, FLT_MAX);
+          pb.rd[q ^ 1][no] = make_float4(nxt_d.x, nxt_d.y, nxt_d.z, u2f(key));
           pb.qs[q ^ 1][no] = make_float4(beta.x, beta.y, beta.z, u2f(depth));
         }
 #endif
