@@ -92,7 +92,7 @@ struct phx_device {
   bool preprocessed = false;
 
   // scene
-  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_elem_normals; DevBuf<uint2> d_spill;
+  DevBuf<PoolElem> d_pool; DevBuf<uint32_t> d_prim_material; DevBuf<float> d_elem_normals; DevBuf<float4> d_elem_shade; DevBuf<uint2> d_spill;
   DevBuf<DevMaterial> d_materials; DevBuf<DevMatLite> d_mat_lite; DevBuf<DevLight> d_lights; DevBuf<DevLightTri> d_light_tris;
   DevScene scene{};
   uint32_t num_materials = 0;
@@ -156,7 +156,7 @@ struct phx_device {
   }
   // HBM held by this device object (phx_stats::device_bytes)
   uint64_t device_bytes() const {
-    uint64_t b = d_pool.bytes() + d_prim_material.bytes() + d_elem_normals.bytes() + d_spill.bytes() + d_materials.bytes() + d_mat_lite.bytes() +
+    uint64_t b = d_pool.bytes() + d_prim_material.bytes() + d_elem_normals.bytes() + d_elem_shade.bytes() + d_spill.bytes() + d_materials.bytes() + d_mat_lite.bytes() +
                  d_lights.bytes() + d_light_tris.bytes() + hit.bytes() + so.bytes() + sd.bytes() + sc.bytes() + pr.bytes() + pn.bytes() +
                  counters.bytes() + dstats.bytes() + pix_xy.bytes() + jitter.bytes() + acc.bytes();
     for (int q = 0; q < 2; ++q) b += ro[q].bytes() + rd[q].bytes() + qs[q].bytes();
@@ -397,7 +397,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if (builder > PHX_BVH_HOST_SAH) return fail(PHX_ERR_ARG, "unknown bvh_builder");
   bool want_host = builder == PHX_BVH_HOST_SAH || (builder == PHX_BVH_AUTO && ntri < 64u);
   GpuBvh g{};
-  DevBuf<uint32_t> d_elem_of_prim;  // any_smooth: pool index of every primitive's triangle record (the normals table is laid out by it)
+  DevBuf<uint32_t> d_elem_of_prim;  // pool index of every primitive's triangle record (the shade records and the normals table are laid out by it)
   if (!want_host) {
     // the triangles go up once (36 B each); the tree is built and stays in HBM (bvh_gpu.hip)
     DevBuf<float> d_abc;
@@ -413,8 +413,8 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
       std::snprintf(msg, sizeof(msg), "forced %s failure (PHX_TEST_FAIL_DEVICE_BUILD)", brc == 1 ? "fatal" : "recoverable");
     }
 #endif
-    if (!brc && any_smooth && d_elem_of_prim.alloc(ntri)) brc = (int)BVH_GPU_RECOVERABLE, std::snprintf(msg, sizeof(msg), "%s", g_error.c_str());
-    if (!brc) brc = build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg), any_smooth ? d_elem_of_prim.p : nullptr);
+    if (!brc && d_elem_of_prim.alloc(ntri)) brc = (int)BVH_GPU_RECOVERABLE, std::snprintf(msg, sizeof(msg), "%s", g_error.c_str());
+    if (!brc) brc = build_bvh8_gpu(d->stream, d_abc.p, d->d_prim_material.p, ntri, &g, msg, sizeof(msg), d_elem_of_prim.p);
     if (brc) {
       // An explicit DEVICE_LBVH request fails loudly, and so does AUTO when the device builder reports anything but a RECOVERABLE cause
       // (a HIP error from a launch or a sync, lost triangles: bugs that a silent 0.6-7 s host build would hide).  Under AUTO a device
@@ -435,7 +435,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
     build_bvh8(abc.data(), ntri, bvh, threads, prim_material.data());
     if ((rc = d->d_pool.upload(bvh.pool))) return rc;
-    if (any_smooth && (rc = d_elem_of_prim.upload(bvh.elem_of_prim))) return rc;
+    if ((rc = d_elem_of_prim.upload(bvh.elem_of_prim))) return rc;
     bvh_depth = bvh.depth; bvh_node_count = bvh.num_nodes; bvh_elems = bvh.pool.size(); bvh_grid = bvh.grid;
     d->bvh_cost_model = bvh.cost; d->bvh_built_on_device = 0;
   } else {
@@ -450,6 +450,10 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if ((rc = d->d_materials.upload(mats))) return rc;
   if ((rc = d->d_lights.upload(lights))) return rc;
   if ((rc = d->d_light_tris.upload(light_tris))) return rc;
+  // what shading reads of a hit triangle, 16 bytes per POOL ELEMENT: geometric normal + material word
+  if ((rc = d->d_elem_shade.alloc(bvh_elems))) return rc;
+  launch_build_shade_recs(d->stream, reinterpret_cast<const TriRec*>(d->d_pool.p), d_elem_of_prim.p, d->d_elem_shade.p, ntri);
+  HIPCHK(hipGetLastError());
   if (any_smooth) {
     // vertex normals by POOL ELEMENT (the index a hit record carries), so that the shade kernels request them with the triangle record and not
     // after it; the smooth light triangles' `prim` becomes a pool index too (shading_normal on the light's face, spt.hpp:212-255)
@@ -459,10 +463,10 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
     launch_permute_normals(d->stream, d_prim_normals.p, d_elem_of_prim.p, d->d_elem_normals.p, ntri);
     launch_remap_light_tris(d->stream, d->d_light_tris.p, (uint32_t)light_tris.size(), d_elem_of_prim.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(d->stream));
   } else {
     d->d_elem_normals.release();
   }
+  HIPCHK(hipStreamSynchronize(d->stream));  // d_elem_of_prim (and the normals in primitive order) go out of scope below
 
   DevScene& sc = d->scene;
   sc.pool = reinterpret_cast<const uint32_t*>(d->d_pool.p);
@@ -470,6 +474,7 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   sc.grid = bvh_grid;
   sc.prim_material = d->d_prim_material.p;
   sc.elem_normals = any_smooth ? d->d_elem_normals.p : nullptr;
+  sc.elem_shade = d->d_elem_shade.p;
   sc.materials = d->d_materials.p;
   sc.lights = d->d_lights.p; sc.light_tris = d->d_light_tris.p; sc.num_lights = (uint32_t)lights.size();
   sc.env_material = s->environment_material;

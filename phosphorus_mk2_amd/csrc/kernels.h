@@ -32,6 +32,9 @@ struct DevScene {
   const TriRec* tris;             // the same pool seen as triangle records (hit records carry pool indices)
   SceneGrid grid;                 // grid of the nodelets' origins
   const uint32_t* prim_material;  // per primitive (scene_t::triangles() order): material | smooth << 31
+  const float4* elem_shade;       // per POOL ELEMENT (indexed like `tris`): what shading needs of a hit triangle in 16 bytes — its geometric normal
+                                  // normalize((v1-v0) x (v2-v0)) (mesh.cpp:201-215, computed once at preprocess by the shade kernels' own expression) and
+                                  // material | smooth << 31 — instead of the 64-byte triangle record (round 6)
   const float* elem_normals;      // 9 floats (n0,n1,n2) per POOL ELEMENT — indexed like `tris`, by the hit's pool index, so that the normals are requested
                                   // WITH the triangle record, not after it (round 6; entries of nodelets are never read) — or nullptr when no face is smooth
   const DevMaterial* materials;
@@ -118,6 +121,7 @@ void launch_shade(hipStream_t stream, const DevScene& sc, const PassBuffers& pb,
 void launch_film(hipStream_t stream, const PassBuffers& pb, uint32_t num_samples, float inv_spp_pps);
 // preprocess: vertex normals from scene_t::triangles() order to pool-element order (elem_of_prim: the builders' map), and the smooth light
 // triangles' `prim` from primitive to pool element (they look their normals up in the same table)
+void launch_build_shade_recs(hipStream_t stream, const TriRec* tris, const uint32_t* elem_of_prim, float4* elem_shade, uint32_t num_prims);
 void launch_permute_normals(hipStream_t stream, const float* prim_normals, const uint32_t* elem_of_prim, float* elem_normals, uint32_t num_prims);
 void launch_remap_light_tris(hipStream_t stream, DevLightTri* light_tris, uint32_t num_light_tris, const uint32_t* elem_of_prim);
 void launch_scatter_film(hipStream_t stream, const PassBuffers& pb, float* device_film, uint32_t film_width);

@@ -818,9 +818,9 @@ __device__ __forceinline__ VertexNormals request_vertex_normals(const DevScene& 
   }
   return N;
 }
-__device__ __forceinline__ v3 shading_normal(const VertexNormals& N, bool smooth, const v3& e0, const v3& e1, float u, float v) {
+__device__ __forceinline__ v3 shading_normal(const VertexNormals& N, bool smooth, const v3& geometric /* DevScene::elem_shade */, float u, float v) {
   if (smooth) { const float w = 1 - u - v; return normalize_inplace(w * N.n0 + u * N.n1 + v * N.n2); }  // the same expression as above
-  return normalize_inplace(cross(e0, e1));
+  return geometric;
 }
 
 __device__ __forceinline__ float luminance(const v3& c) {  // color::y, src/utils/color.hpp:13-16
@@ -882,11 +882,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
     const uint32_t tri = f2u(h.w);
     const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
     if (tri != 0xffffffffu) {
-      const TriRec T = sc.tris[tri];
-      const uint32_t pm = T.material;
+      const float4 S = sc.elem_shade[tri];  // (geometric normal, material | smooth << 31): 16 bytes of the hit triangle instead of its 64-byte record
+      const uint32_t pm = f2u(S.w);
       const v3 p = o + d * h.x;            // hits.p = p + wi*d
       const v3 wo = -d;                    // hits.wi = -wi
-      const v3 n = shading_normal(sc, tri, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+      const v3 n = (pm >> 31) != 0 ? shading_normal(sc, tri, true, v3(0.0f), v3(0.0f), h.y, h.z) : v3(S.x, S.y, S.z);
       // material_t::evaluate (material.cpp:419-458): the closure list at this hit.  A constant recipe is read from the table; a
       // material with a hit-dependent weight (glass: Fresnel-driven mix) gets its weights resolved for (n, hits.wi) first.
       const DevMaterial* mp = &sc.materials[pm & 0x7fffffffu];
@@ -1037,7 +1037,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #define PHX_SHADE_PREFETCH_PERHIT 0  /* the same two stages in the per-hit (glass) instantiations: measured worthless in round 5 (profiles/r05_c_shade_prefetch_glass_ab.log) */
 #endif
 #ifndef PHX_SHADE_TRI_LDS
-#define PHX_SHADE_TRI_LDS 1  /* instantiations without prefetch stages (per-hit closures): the sort phase keeps each hit's pool index beside the permutation (16 KB of LDS), so that a round requests the triangle record and the vertex normals WITH the hit record and the ray instead of after the hit record has landed */
+#define PHX_SHADE_TRI_LDS 1  /* the sort phase keeps each hit's pool index beside the permutation (16 KB of LDS), so that a round requests the hit triangle's shade record (and, where nothing is prefetched, its vertex normals) WITH the hit record and the ray instead of after the hit record has landed */
 #endif
 #ifndef PHX_SCALAR_F_PERHIT
 #define PHX_SCALAR_F_PERHIT 1  /* the per-hit (glass) instantiations read the recipe through the scalar cache too: with the ring append the kernel has the registers (127 / 123 VGPRs, no scratch; round 5: 16 B of scratch): closed showroom -4.4 %, glass showroom -2.9 % shade time (profiles/r06_i_perhit_knobs_ab.log) */
@@ -1180,7 +1180,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #endif
   __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
   __shared__ uint16_t perm[WINDOW];
-  constexpr bool TRI_LDS = PHX_SHADE_TRI_LDS && !(PHX_SHADE_PREFETCH >= 1 && (!PERHIT || PHX_SHADE_PREFETCH_PERHIT >= 1));  // = !STAGE1 below
+  constexpr bool TRI_LDS = PHX_SHADE_TRI_LDS != 0;
   __shared__ uint32_t tri_sorted[TRI_LDS ? WINDOW : 1];  // the hit's pool index (0xffffffff = miss) at its sorted position
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   if (blockIdx.x == 0 && threadIdx.x == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
@@ -1248,8 +1248,8 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     // and the round trip of the workgroup's atomics); at the append a thread holds almost nothing but its outputs, so the twelve registers of
     // the next records cost no occupancy there, and the two waits overlap.  (Round 3 requested them at the START of round k and held them
     // across the closure code: 5-12 VGPRs where the kernel has none to spare, 1.2 of 42.7 ms: profiles/r03_q_prefetch_ab.log.)
-    uint32_t next_i = 0; bool next_live = false;
-    float4 next_h = make_float4(0.f, 0.f, 0.f, 0.f), next_a = next_h, next_b = next_h;
+    uint32_t next_i = 0, next_tri = 0xffffffffu; bool next_live = false;
+    float4 next_h = make_float4(0.f, 0.f, 0.f, 0.f), next_a = next_h, next_b = next_h, next_S = next_h;
     constexpr bool DYN = PHX_SHADE_RING && PHX_SHADE_DYN_SLICES;
     // DYN: slices of 64 sorted slots, handed out by an LDS counter; the live slots are a prefix of the sorted window, so are the live slices
     const uint32_t nslices = (min((uint32_t)WINDOW, count - base) + 63u) >> 6;
@@ -1271,6 +1271,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         if (next_live) {
           next_h = pb.hit[next_i];
           if (!FIRST) { next_a = pb.ro[q][next_i]; next_b = pb.rd[q][next_i]; }
+          if constexpr (TRI_LDS) {  // the shade record no longer waits for the hit record: its index is in LDS (four registers across the append)
+            next_tri = tri_sorted[sorted_slot(k)];
+            if (next_tri != 0xffffffffu) next_S = sc.elem_shade[next_tri];
+          }
         }
       }
     };
@@ -1278,12 +1282,11 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
     // the first stage has landed, and travels while this round's queue entries are stored; the path state — since round 6 a queue record like
     // the ray, no longer a gather by path id — goes with it (four registers that need not live across the append)
     float4 next_bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // FIRST: state_t::reset: beta = 1, depth = 0
-    TriRec next_T{};
     auto request_round_dependents = [&]() {
       if (next_live) {
         if (!FIRST) next_bd = pb.qs[q][next_i];
         const uint32_t tri = f2u(next_h.w);
-        if (tri != 0xffffffffu) next_T = sc.tris[tri];
+        if constexpr (!TRI_LDS) { if (tri != 0xffffffffu) next_S = sc.elem_shade[tri]; }
       }
     };
     // (with per-hit closure weights — glass — either stage costs the kernel 16 B of scratch and buys nothing: 41.7-42.1 ms with, 41.9-42.2
@@ -1312,10 +1315,13 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         if constexpr (STAGE1) h = next_h; else h = pb.hit[i];
         // TRI_LDS: the hit's pool index comes from the sort phase (LDS), so its triangle record and vertex normals are requested HERE, beside the
         // hit record and the ray, not after the hit record has landed (one memory round trip less on the critical path of a round)
-        uint32_t tri_early = 0xffffffffu; TriRec T_early{}; VertexNormals VN_early{v3(0.0f), v3(0.0f), v3(0.0f)};
-        if constexpr (TRI_LDS) {
+        uint32_t tri_early = 0xffffffffu; float4 S_early = make_float4(0.f, 0.f, 0.f, 0.f); VertexNormals VN_early{v3(0.0f), v3(0.0f), v3(0.0f)};
+        if constexpr (TRI_LDS && STAGE1) {
+          tri_early = next_tri; S_early = next_S;
+          if (tri_early != 0xffffffffu) VN_early = request_vertex_normals(sc, tri_early);
+        } else if constexpr (TRI_LDS) {
           tri_early = tri_sorted[sorted_slot(k)];
-          if (tri_early != 0xffffffffu) { T_early = sc.tris[tri_early]; VN_early = request_vertex_normals(sc, tri_early); }
+          if (tri_early != 0xffffffffu) { S_early = sc.elem_shade[tri_early]; VN_early = request_vertex_normals(sc, tri_early); }
         }
         if (FIRST) {
           v3 co, cd;
@@ -1343,13 +1349,13 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         if (tri != 0xffffffffu) {
           hit_surface = true;
           VertexNormals VN;
-          TriRec T;
-          if constexpr (TRI_LDS) { VN = VN_early; T = T_early; }
-          else { VN = request_vertex_normals(sc, tri); if constexpr (STAGE1) T = next_T; else T = sc.tris[tri]; }
-          const uint32_t pm = T.material;
+          float4 S;  // (geometric normal, material | smooth << 31): DevScene::elem_shade
+          if constexpr (TRI_LDS) { VN = VN_early; S = S_early; }
+          else { VN = request_vertex_normals(sc, tri); if constexpr (STAGE1) S = next_S; else S = sc.elem_shade[tri]; }
+          const uint32_t pm = f2u(S.w);
           p = o + d * h.x;            // hits.p = p + wi*d
           wo = -d;                    // hits.wi = -wi
-          n = shading_normal(VN, (pm >> 31) != 0, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), h.y, h.z);
+          n = shading_normal(VN, (pm >> 31) != 0, v3(S.x, S.y, S.z), h.y, h.z);
           mat = pm & 0x7fffffffu;  // material_t::evaluate (material.cpp:419-458): the closure recipe at this hit
           if (pb.pn && (FIRST || depth == 0)) pb.pn[path] = make_float4(n.x, n.y, n.z, 1.0f);
           if (depth == 0 || specular) { const DevMaterial& m = sc.materials[mat]; add_e = v3(m.ex, m.ey, m.ez); add_rad = true; }  // spt.hpp:177-179
@@ -1785,6 +1791,15 @@ void launch_trace_primary(hipStream_t stream, const DevScene& sc, const PassBuff
   else hipLaunchKernelGGL(k_trace_primary<1>, g, b, lds, stream, sc, pb, npaths, sample0, q, sq);
 }
 namespace {
+__global__ void k_build_shade_recs(const TriRec* __restrict__ tris, const uint32_t* __restrict__ elem_of_prim, float4* __restrict__ elem_shade, uint32_t n) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t e = elem_of_prim[p];
+  if (e == 0xffffffffu) return;
+  const TriRec T = tris[e];
+  const v3 gn = shading_normal(DevScene{}, e, false, v3(T.e0x, T.e0y, T.e0z), v3(T.e1x, T.e1y, T.e1z), 0.0f, 0.0f);  // the flat face's normal, by the expression the shade kernels used per hit
+  elem_shade[e] = make_float4(gn.x, gn.y, gn.z, u2f(T.material));
+}
 __global__ void k_permute_normals(const float* __restrict__ prim_normals, const uint32_t* __restrict__ elem_of_prim, float* __restrict__ elem_normals, uint32_t n) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
@@ -1798,6 +1813,9 @@ __global__ void k_remap_light_tris(DevLightTri* __restrict__ lt, uint32_t n, con
   if (i < n && lt[i].smooth) lt[i].prim = elem_of_prim[lt[i].prim];
 }
 }  // namespace
+void launch_build_shade_recs(hipStream_t stream, const TriRec* tris, const uint32_t* elem_of_prim, float4* elem_shade, uint32_t num_prims) {
+  if (num_prims) hipLaunchKernelGGL(k_build_shade_recs, dim3((num_prims + 255) / 256), dim3(256), 0, stream, tris, elem_of_prim, elem_shade, num_prims);
+}
 void launch_permute_normals(hipStream_t stream, const float* prim_normals, const uint32_t* elem_of_prim, float* elem_normals, uint32_t num_prims) {
   if (num_prims) hipLaunchKernelGGL(k_permute_normals, dim3((num_prims + 255) / 256), dim3(256), 0, stream, prim_normals, elem_of_prim, elem_normals, num_prims);
 }
