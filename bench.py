@@ -337,15 +337,17 @@ def roofline(acc, steps, work, tag, ref_visits, capture_is_this_frame=True):
     return roof
 
 
-# algorithmic bytes per shaded queue entry in the device's layout: in — hit 16, ray 32, path state 16,
-# triangle record 64 (one 64-B element of the pool); out — next ray 32 + path state 16 for a survivor, 48 for an NEE ray.
-# The camera rays' entries (the first launch of a pass) read no ray and no path state — both are rebuilt — and write the path's radiance (16).
-SHADE_BYTES_IN, SHADE_BYTES_IN_CAMERA, SHADE_BYTES_SURVIVOR, SHADE_BYTES_NEE = 16 + 32 + 16 + 64, 16 + 64 + 16, 32 + 16, 48
+# algorithmic bytes per shaded queue entry in the device's layout: in — hit 16, ray 32, path state 16 (a queue
+# record beside the ray since round 6), the hit triangle's shade record 16 (geometric normal + material word; until round 6 the 64-B
+# triangle record of the pool); out — next ray 32 + path state 16 for a survivor, 48 for an NEE ray.  The camera rays' entries (the
+# first launch of a pass) read no ray and no path state — both are rebuilt — and write the path's radiance (16).  Vertex normals of
+# smooth faces (36 per hit on mesh scenes) are not counted.
+SHADE_BYTES_IN, SHADE_BYTES_IN_CAMERA, SHADE_BYTES_SURVIVOR, SHADE_BYTES_NEE = 16 + 32 + 16 + 16, 16 + 16 + 16, 32 + 16, 48
 
 
 def shade_roofline(acc, steps, st, tag):
     """the shade/NEE/integrate kernel (k_shade_g for general closures): HBM-stream roofline.  One launch shades every entry of a
-    ray queue: algorithmic bytes = entries x (hit + ray + state + triangle record) + survivors x (next ray + state) + NEE rays x 48,
+    ray queue: algorithmic bytes = entries x (hit + ray + state + shade record) + survivors x (next ray + state) + NEE rays x 48,
     all counted by the device in this run."""
     nl = max(1, acc["shade_launches"])
     t = acc["shade_kernel_ms"] * 1e-3

@@ -1204,7 +1204,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #if PHX_SHADE_KEY_PROBE
       key[k] = tri[k] == 0xfffffffeu ? NB + 1u : tri[k] != 0xffffffffu ? 0u : (uint32_t)NB;  // probe builds only: what the material gather of the sort phase costs (one-material scenes)
 #else
-      key[k] = tri[k] == 0xfffffffeu ? NB + 1u : tri[k] != 0xffffffffu ? (sc.tris[tri[k]].material & (NB - 1u)) : (uint32_t)NB;
+      key[k] = tri[k] == 0xfffffffeu ? NB + 1u : tri[k] != 0xffffffffu ? (f2u(sc.elem_shade[tri[k]].w) & (NB - 1u)) : (uint32_t)NB;  // the material word of the 16-byte shade record (four to a sector; the shading rounds read the same records)
 #endif
     }
   };

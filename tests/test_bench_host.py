@@ -120,7 +120,7 @@ def test_shade_roofline_counts_algorithmic_bytes_per_entry():
     r = bench.shade_roofline(acc, 1, {"shade_general": 1}, None)
     # 500 M camera entries (hit + triangle record in, radiance out: no ray, no path state) + 100 M later entries, each a survivor of a shade launch
     alg = 500e6 * bench.SHADE_BYTES_IN_CAMERA + 100e6 * bench.SHADE_BYTES_IN + 100e6 * bench.SHADE_BYTES_SURVIVOR + 400e6 * bench.SHADE_BYTES_NEE
-    assert bench.SHADE_BYTES_IN == 128 and bench.SHADE_BYTES_IN_CAMERA == 96
+    assert bench.SHADE_BYTES_IN == 80 and bench.SHADE_BYTES_IN_CAMERA == 48
     assert r["kernel"] == "k_shade_g" and r["bound"] == "hbm" and abs(r["achieved"] - alg / 0.040 / 1e9) < 1e-6 and 0 < r["frac"] <= 1
 
 
