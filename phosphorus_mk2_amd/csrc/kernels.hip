@@ -31,7 +31,7 @@ namespace phx {
 #define PHX_SHADE_TIMING 0  /* probe builds only: s_memtime around k_shade_g's sort phase and shading rounds, summed into DevStats fields the count build uses (block_append2 below tests it too) */
 #endif
 #ifndef PHX_SHADE_PREFETCH
-#define PHX_SHADE_PREFETCH 2  /* k_shade_g: 1 = hit record and ray of the next round are requested before this round's append; 2 = and path state + triangle record right after it (35.9 / 35.3 / 34.8 ms for 0 / 1 / 2: profiles/r05_c_shade_prefetch_ab.log) */
+#define PHX_SHADE_PREFETCH 2  /* k_shade_g: 1 = hit record and ray of the next round are requested before this round's append; 2 = and the path state (a queue record since round 6) right after it — the hit triangle's 16-byte shade record goes with stage 1, its index being in LDS (PHX_SHADE_TRI_LDS) — (35.9 / 35.3 / 34.8 ms for 0 / 1 / 2: profiles/r05_c_shade_prefetch_ab.log) */
 #endif
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
@@ -806,7 +806,7 @@ __device__ __forceinline__ v3 shading_normal(const DevScene& sc, uint32_t elem /
   }
   return normalize_inplace(cross(e0, e1));  // (v1-v0) x (v2-v0), never flipped (mesh.cpp:201-215)
 }
-// k_shade_g: the three vertex normals of the hit's pool element are requested TOGETHER WITH its triangle record — whether the face is smooth
+// k_shade_g: the three vertex normals of the hit's pool element are requested TOGETHER WITH its shade record — whether the face is smooth
 // is a bit of that record — and used or dropped when it has landed (flat faces of a scene with smooth ones pay a 36-byte gather for nothing;
 // scenes without smooth faces have no table and no request)
 struct VertexNormals { v3 n0, n1, n2; };
@@ -1278,9 +1278,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         }
       }
     };
-    // second stage (PHX_SHADE_PREFETCH 2): the triangle record, which depends on the hit record, is requested right after the append, when
-    // the first stage has landed, and travels while this round's queue entries are stored; the path state — since round 6 a queue record like
-    // the ray, no longer a gather by path id — goes with it (four registers that need not live across the append)
+    // second stage (PHX_SHADE_PREFETCH 2): requested right after the append, travelling while this round's queue entries are stored: the path
+    // state — since round 6 a queue record like the ray, no longer a gather by path id: four registers that need not live across the append —
+    // and, in builds without PHX_SHADE_TRI_LDS, the shade record, whose index then has to wait for the hit record
     float4 next_bd = make_float4(1.0f, 1.0f, 1.0f, u2f(0u));  // FIRST: state_t::reset: beta = 1, depth = 0
     auto request_round_dependents = [&]() {
       if (next_live) {
@@ -1313,7 +1313,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         float4 a, b, bd;
         float4 h;
         if constexpr (STAGE1) h = next_h; else h = pb.hit[i];
-        // TRI_LDS: the hit's pool index comes from the sort phase (LDS), so its triangle record and vertex normals are requested HERE, beside the
+        // TRI_LDS: the hit's pool index comes from the sort phase (LDS), so its shade record and vertex normals are requested HERE, beside the
         // hit record and the ray, not after the hit record has landed (one memory round trip less on the critical path of a round)
         uint32_t tri_early = 0xffffffffu; float4 S_early = make_float4(0.f, 0.f, 0.f, 0.f); VertexNormals VN_early{v3(0.0f), v3(0.0f), v3(0.0f)};
         if constexpr (TRI_LDS && STAGE1) {
@@ -1377,7 +1377,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
           pb.pr[path] = make_float4(rad.x, rad.y, rad.z, 0.0f);
         }
       }
-      PHX_PHASE(1)  // hit record, ray, path state, triangle record, normals: requested and landed; emission added
+      PHX_PHASE(1)  // hit record, ray, path state, shade record, normals: requested and landed; emission added
       // the hit's tangent frame (orthogonal_base_t): once per hit, for the NEE evaluation and the BSDF sample
       const Frame fr(hit_surface ? n : v3(0.0f, 1.0f, 0.0f));
       // ---- next-event estimation: sampler_t::fresh_light_samples + light_sampler_t (sampling.cpp:160-179, spt.hpp:95-149)
@@ -1468,7 +1468,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
         // both queues in one go: two barriers and two concurrent atomics per round (appending the NEE ray before roulette and sampling
         // — shorter live ranges, four barriers, two atomics in a row — was right while the kernel fought for occupancy; at 4 waves per SIMD
         // either way, the 10 registers are free and the round trip is not: 43.1 -> 41.5 ms, profiles/r03_zzc_append2_ab.log)
-        PHX_PHASE(3)  // roulette, bsdf_sample, path state store
+        PHX_PHASE(3)  // roulette, bsdf_sample
         k_next = DYN ? take_slice() : k + 1u;
         if constexpr (STAGE1) request_round(k_next);  // in flight across the append (the append waits for LDS traffic only)
 #if PHX_SHADE_RING
