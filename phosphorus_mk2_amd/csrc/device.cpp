@@ -104,6 +104,7 @@ struct phx_device {
   DevBuf<uint32_t> counters; DevBuf<DevStats> dstats; DevBuf<uint32_t> pix_xy; DevBuf<float2> jitter; DevBuf<float> acc;
   uint64_t jitter_seed = 0; uint32_t jitter_spp = 0;  // what the jitter table on the device was made for
   float* h_acc = nullptr; size_t h_acc_n = 0;  // pinned staging for add_tile
+  uint32_t* h_qlen = nullptr; size_t h_qlen_n = 0;  // pinned, device-visible: queue lengths published by k_trace, one word per (pass, step) of a batch (enqueue_batch)
   std::vector<phx_tile> pix_xy_tiles;          // the tiles pix_xy currently describes
 
   // frame
@@ -143,6 +144,7 @@ struct phx_device {
     if (driver.joinable()) driver.join();
     for (auto e : direct.events) (void)hipEventDestroy(e);
     if (h_acc) (void)hipHostFree(h_acc);
+    if (h_qlen) (void)hipHostFree(h_qlen);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -988,10 +990,41 @@ int phx_device::enqueue_batch(BatchLaunches& g, const PassBuffers& B0, uint32_t 
     g.timed.push_back({begin, (size_t)last_end, kind});
     return PHX_OK;
   };
-  for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+  // Shade grids sized by the queue, not by its capacity.  k_shade runs one workgroup per 1024 entries and the host does not know the queue
+  // lengths (they stay on the device): a grid for the capacity is 230 k workgroups at EVERY step of the bench frame, nearly all of them
+  // empty from the third step on — 0.25 ms per launch for nothing.  k_trace of step b publishes the length of the queue it traces in pinned
+  // host memory; the queue of a later step is never longer, so the shade launch of step b + 1 is sized by it.  The host waits for that word
+  // before it enqueues the launch — while the device still has k_trace(b), k_shade(b) and k_trace(b + 1) in its queue: it never runs dry
+  // (measured: k_shade 8.6 -> 7.5 ms on the bench frame, profiles/r06_v_grid_by_queue_ab.log).
+  // (PHX_SHADE_GRID_BY_QUEUE=0: grids for the capacity, everything enqueued at once, as before.)
+  static const bool grid_by_queue = [] { const char* v = std::getenv("PHX_SHADE_GRID_BY_QUEUE"); return !(v && v[0] == '0'); }();
+  const uint32_t depth = opt.path_depth, npasses = (spp + S - 1) / S;
+  if (grid_by_queue) {
+    const size_t need = (size_t)npasses * depth;
+    if (need > h_qlen_n) {
+      if (h_qlen) (void)hipHostFree(h_qlen);
+      h_qlen = nullptr; h_qlen_n = 0;
+      HIPCHK(hipHostMalloc((void**)&h_qlen, need * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+      h_qlen_n = need;
+    }
+    for (size_t k = 0; k < need; ++k) __atomic_store_n(&h_qlen[k], 0xffffffffu, __ATOMIC_RELAXED);  // the previous batch has been joined (render_batch)
+  }
+  auto queue_bound = [&](uint32_t pass, uint32_t step, uint32_t cap) -> uint32_t {  // length of the ray queue k_trace(step) of this pass traced, once it has started
+    const volatile uint32_t* w = &h_qlen[(size_t)pass * depth + step];
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+      const uint32_t v = __atomic_load_n(const_cast<const uint32_t*>(w), __ATOMIC_ACQUIRE);
+      if (v != 0xffffffffu) return std::min(v, cap);
+      // never for ever: a device that has stopped (fault, watchdog) is found by the synchronisation behind the batch — size for the capacity and go on
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return cap;
+    }
+  };
+  uint32_t pass = 0;
+  for (uint32_t s0 = 0; s0 < spp; s0 += S, ++pass) {
     const uint32_t ns = std::min(S, spp - s0);
     const uint32_t cap = P * ns;
     B.num_samples = ns;
+    B.qlen_out = nullptr;
     if ((rc = timed_launch(2, [&]() { launch_begin_pass(stream, B, ns); }))) return rc;
     int q = 0;
     for (uint32_t bounce = 0; bounce < opt.path_depth; ++bounce) {  // a path takes at most path_depth steps (spt.hpp:314)
@@ -999,8 +1032,15 @@ int phx_device::enqueue_batch(BatchLaunches& g, const PassBuffers& B0, uint32_t 
       const int sq_read = (int)((bounce + 1) & 1), sq_write = (int)(bounce & 1);
       if (bounce == 0) {  // the camera rays: one packet walk per 64 x n of them
         if ((rc = timed_launch(4, [&]() { launch_trace_primary(stream, scene, B, cap, s0, q, sq_read); }))) return rc;
-      } else if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, 1, cap); }))) return rc;
-      if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, cap, s0, bounce == 0); }))) return rc;
+      } else {
+        B.qlen_out = grid_by_queue ? h_qlen + (size_t)pass * depth + bounce : nullptr;
+        if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, sq_read, 1, 1, cap); }))) return rc;
+        B.qlen_out = nullptr;
+      }
+      // step 0: the capacity.  Step 1: the length k_trace(1) — the longest launch of a pass, enqueued just above — publishes as it starts.
+      // Later steps: the length published one step earlier (the device then still has two launches queued while the host waits).
+      const uint32_t shade_cap = (grid_by_queue && bounce >= 1) ? std::max(queue_bound(pass, bounce == 1 ? 1u : bounce - 1, cap), 1u) : cap;
+      if ((rc = timed_launch(3, [&]() { launch_shade(stream, scene, B, q, sq_write, shade_cap, s0, bounce == 0); }))) return rc;
       q ^= 1;
     }
     if ((rc = timed_launch(0, [&]() { launch_trace(stream, scene, B, q, (int)((opt.path_depth - 1) & 1), 0, 1, cap); }))) return rc;

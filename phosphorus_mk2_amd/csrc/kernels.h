@@ -98,6 +98,7 @@ struct PassBuffers {
   uint32_t xstride;
   uint32_t normals_offset;    // offset of channel "normals" inside a pixel, 0 = off
   uint64_t seed;
+  uint32_t* qlen_out;         // k_trace: host-visible word that receives the length of the ray queue it traces (device.cpp sizes the next shade grids by it), or nullptr
 };
 
 // shape of a k_trace launch on a scene (reported through phx_stats so that tests can assert which plan a tree ran with)

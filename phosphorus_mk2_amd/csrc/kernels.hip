@@ -534,6 +534,9 @@ __global__ void __launch_bounds__(BLOCK, 8) k_trace(DevScene sc, PassBuffers pb,
     if (do_closest) { pb.counters[(q ^ 1) * CNT_STRIDE] = 0; pb.counters[CNT_SHADOW + (sq ^ 1) * CNT_STRIDE] = 0; }
     if (n_closest) atomicAdd(&pb.stats->rays_closest, (unsigned long long)n_closest);
     if (n_shadow) atomicAdd(&pb.stats->rays_shadow, (unsigned long long)n_shadow);
+    // the host sizes the grids of the NEXT steps' shade launches by this length (queues never grow from one step to the next): a k_shade
+    // grid sized for the queue's capacity launches 230 k workgroups at every step, nearly all of them empty from the third step on
+    if (do_closest && pb.qlen_out) { __hip_atomic_store(pb.qlen_out, n_closest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
   if (n_shadow == 0u && n_closest == 0u) return;
   DynQueue dq{};
