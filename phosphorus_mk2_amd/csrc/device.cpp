@@ -311,7 +311,9 @@ static int preprocess_impl(phx_device* d, const phx_scene* s) {
   if (!d || !s) return fail(PHX_ERR_ARG, "preprocess: null argument");
   if (d->running) return fail(PHX_ERR_STATE, "preprocess while a frame is running");
   if (!s->meshes || !s->materials || s->num_materials == 0) return fail(PHX_ERR_ARG, "scene without meshes/materials");
-  if (!(std::fabs(s->camera.aperture_radius) <= FLT_MAX) || !(std::fabs(s->camera.focal_distance) <= FLT_MAX)) return fail(PHX_ERR_ARG, "camera: aperture radius / focal distance not finite");
+  // (camera_t's constructor leaves focal_distance uninitialised, entities/camera.hpp:31-36: it means something only behind a lens)
+  if (!(std::fabs(s->camera.aperture_radius) <= FLT_MAX) || (s->camera.aperture_radius != 0.0f && !(std::fabs(s->camera.focal_distance) <= FLT_MAX)))
+    return fail(PHX_ERR_ARG, "camera: aperture radius / focal distance not finite");
   if (s->camera.film_width == 0 || s->camera.film_height == 0 || s->camera.film_width > 65535 || s->camera.film_height > 65535)
     return fail(PHX_ERR_ARG, "film size out of range");
   if (s->environment_material >= (int32_t)s->num_materials) return fail(PHX_ERR_ARG, "environment material out of range");

@@ -757,6 +757,11 @@ def test_error_behaviour(xpu):
     lens = scenes.cornell(32, 32); lens.camera.aperture_radius = float("inf")  # a finite aperture is the thin lens (test_thin_lens_*)
     with pytest.raises(xpu.DeviceError):
         dev.preprocess(lens)
+    pin = scenes.cornell(32, 32); pin.camera.focal_distance = float("nan")  # camera_t() leaves it uninitialised: it means nothing without a lens
+    dev.preprocess(pin)
+    lens.camera.aperture_radius = 0.1; lens.camera.focal_distance = float("nan")
+    with pytest.raises(xpu.DeviceError):
+        dev.preprocess(lens)
     assert xpu.HipDevice.discover(xpu.Options(host_only=True)) == []
     dev.close()
 
