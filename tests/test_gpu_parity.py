@@ -1049,6 +1049,26 @@ def test_append_ring_timeout_fails_the_frame_instead_of_hanging(xpu, orc):
     assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and bits_equal(film[..., :3][fin], ref[..., :3][fin])
 
 
+def test_shade_grids_sized_by_the_queue_render_the_same_film(xpu):
+    """enqueue_batch sizes the shade launches of step b + 1 by the queue length k_trace(b) publishes in pinned host memory (a grid for the
+    capacity is 230 k mostly empty workgroups per launch on the bench frame); PHX_SHADE_GRID_BY_QUEUE=0 (read once per process) enqueues
+    everything at once with grids for the capacity, as before.  Same film, same counts — in several passes too, and on the general kernel"""
+    import hashlib, os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from phosphorus_mk2_amd import scenes, xpu\n"
+            "for sc, kw in ((scenes.soup(20000, width=320, height=200), dict(spp=24, samples_in_flight=9)), (scenes.multi_material_soup(4000, width=96, height=64), dict(spp=9))):\n"
+            "    film, st = xpu.render(sc, seed=4, depth=7, **kw)\n"
+            "    print('R', hashlib.sha1(film.tobytes()).hexdigest(), st['rays_closest'], st['rays_shadow'], st['shade_launches'])\n") % ROOT
+    runs = []
+    for knob in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=dict(os.environ, PHX_SHADE_GRID_BY_QUEUE=knob))
+        assert r.returncode == 0, r.stderr[-500:]
+        runs.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith("R ")])
+    assert len(runs[0]) == 2 and runs[0] == runs[1], runs
+    assert int(runs[0][0][3]) == 3 * 7  # three passes (9 + 9 + 6 samples) of seven steps
+
+
 def test_frames_without_kernel_timing_render_the_same_film(xpu):
     """PHX_KERNEL_TIMING=0 (a probe knob, read once per process): no HIP events between the launches — phx_stats carries no kernel times,
     the film and the ray counts are the ones of a timed frame"""
