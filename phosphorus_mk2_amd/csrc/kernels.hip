@@ -1042,6 +1042,9 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
 #ifndef PHX_SHADE_TRI_LDS
 #define PHX_SHADE_TRI_LDS 1  /* the sort phase keeps each hit's pool index beside the permutation (16 KB of LDS), so that a round requests the hit triangle's shade record (and, where nothing is prefetched, its vertex normals) WITH the hit record and the ray instead of after the hit record has landed */
 #endif
+#ifndef PHX_SHADE_FIRST_SORT
+#define PHX_SHADE_FIRST_SORT 0  /* 1: the camera entries' launch sorts its windows by material like every other.  0: it does not — the 64 lanes of a wave are 64 samples of ONE pixel there, which see one material (two or three on a silhouette) without any sorting */
+#endif
 #ifndef PHX_SCALAR_F_PERHIT
 #define PHX_SCALAR_F_PERHIT 1  /* the per-hit (glass) instantiations read the recipe through the scalar cache too: with the ring append the kernel has the registers (127 / 123 VGPRs, no scratch; round 5: 16 B of scratch): closed showroom -4.4 %, glass showroom -2.9 % shade time (profiles/r06_i_perhit_knobs_ab.log) */
 #endif
@@ -1220,7 +1223,18 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #endif
     __syncthreads();
     uint32_t keys[ITEMS], tri_[ITEMS];
-    request_tris(base, tri_); request_keys(tri_, keys);
+    request_tris(base, tri_);
+    if constexpr (FIRST && !PHX_SHADE_FIRST_SORT) {
+      // the camera entries: queue order IS pixel order (a wave = 64 samples of one pixel: one material, a few on a silhouette) — no sort, the
+      // identity permutation; the slots past the end of the queue are the window's last ones as they are after a sort
+      if constexpr (TRI_LDS) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) tri_sorted[k * BLOCK + threadIdx.x] = tri_[k];
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) perm[k * BLOCK + threadIdx.x] = (uint16_t)(k * BLOCK + threadIdx.x);
+    } else {
+    request_keys(tri_, keys);
     uint32_t ranks[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) ranks[k] = atomicAdd(&bucket[keys[k]], 1u);
@@ -1239,6 +1253,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
       const uint32_t at = bucket[keys[k]] + ranks[k];
       perm[at] = (uint16_t)(k * BLOCK + threadIdx.x);
       if constexpr (TRI_LDS) tri_sorted[at] = tri_[k];
+    }
     }
     __syncthreads();
     PHX_PHASE(0)  // the window's sort by material
