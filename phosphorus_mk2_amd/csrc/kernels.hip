@@ -840,6 +840,10 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_D) __attribute__((amdgpu_waves
   constexpr int MAXL = MATS == 2 ? 1 : 8;
   constexpr int PHX_SHADE_BLOCK = PHX_SHADE_BLOCK_D;
   __shared__ uint32_t lds_cnt[2 * ((PHX_SHADE_BLOCK >> 6) + 1)];
+  // a k_trace wave that hit its watchdog left rays untraced: their hit records are whatever the buffer held (an earlier step's, an earlier
+  // scene's) — the frame is reported as failed anyway (device.cpp), so nothing is shaded, nothing appended, and the queues of the following
+  // steps are empty
+  if (pb.stats->watchdog | pb.stats->ring_watchdog) return;
   const uint32_t count = pb.counters[q * CNT_STRIDE];
   const uint32_t i = blockIdx.x * PHX_SHADE_BLOCK + threadIdx.x;
   if (i == 0) zero_cursors(pb.counters);  // the next k_trace pulls its chunks from here
@@ -1186,6 +1190,7 @@ __global__ void __launch_bounds__(PHX_SHADE_BLOCK_G) __attribute__((amdgpu_waves
 #endif
   __shared__ uint32_t bucket[NB + 2];  // [material mod NB], [NB] misses, [NB + 1] slots past the end of the queue
   __shared__ uint16_t perm[WINDOW];
+  if (pb.stats->watchdog | pb.stats->ring_watchdog) return;  // (k_shade above: a step whose trace did not finish is not shaded; the frame fails)
   constexpr bool TRI_LDS = PHX_SHADE_TRI_LDS != 0;
   __shared__ uint32_t tri_sorted[TRI_LDS ? WINDOW : 1];  // the hit's pool index (0xffffffff = miss) at its sorted position
   const uint32_t count = pb.counters[q * CNT_STRIDE];
